@@ -1,0 +1,52 @@
+# Builds, in-tree:
+#   raytracer_amd/lib/libmirt.so        the HIP engine behind the C ABI of include/mirt.h (gfx950)
+#   raytracer_amd/lib/libmirt_host.so   the C++ drop-in surface (Scene/Camera/Config, loader, BVH, PPM)
+#   raytracer_amd/bin/raytracer         the command line of the reference, rendering on the GPU
+#   oracle/liboracle.so, oracle/_ref/*  the CPU checker and the reference build (test infrastructure)
+
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+
+LIB := raytracer_amd/lib
+BIN := raytracer_amd/bin
+CSRC := raytracer_amd/csrc
+HOST := raytracer_amd/host
+
+ENGINE_SRCS := $(wildcard $(CSRC)/*.hip)
+ENGINE_HDRS := $(wildcard $(CSRC)/*.h) include/mirt.h include/mirt_rng.h
+HOST_SRCS := $(HOST)/mirt_math.cpp $(HOST)/scene_loader.cpp $(HOST)/image_io.cpp $(HOST)/flatten.cpp \
+             $(HOST)/render.cpp $(HOST)/capi.cpp
+HOST_HDRS := $(wildcard $(HOST)/*.h) include/mirt.h
+
+HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function \
+            -ffp-contract=on $(EXTRA_HIPFLAGS)
+# no FMA contraction on the host: the matrices and boxes computed here are compared bit for bit
+# with the reference's
+HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra -Iinclude -I$(HOST)
+
+.PHONY: all engine host cli oracle clean
+all: engine host cli oracle
+
+engine: $(LIB)/libmirt.so
+host: $(LIB)/libmirt_host.so
+cli: $(BIN)/raytracer
+
+$(LIB) $(BIN):
+	mkdir -p $@
+
+$(LIB)/libmirt.so: $(ENGINE_SRCS) $(ENGINE_HDRS) | $(LIB)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINE_SRCS)
+
+$(LIB)/libmirt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIB)/libmirt.so | $(LIB)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -L$(LIB) -lmirt -Wl,-rpath,'$$ORIGIN'
+
+$(BIN)/raytracer: $(HOST)/main.cpp $(LIB)/libmirt_host.so | $(BIN)
+	$(CXX) $(HOSTFLAGS) -o $@ $(HOST)/main.cpp -L$(LIB) -lmirt_host -lmirt -Wl,-rpath,'$$ORIGIN/../lib'
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -rf $(LIB) $(BIN)
+	$(MAKE) -C oracle clean

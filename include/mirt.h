@@ -1,0 +1,240 @@
+/* mirt.h -- C ABI of the MI355X (gfx950) ray-tracing engine.
+ *
+ * The reference renderer has no FFI: its render hot path is entered through one free function,
+ *     Image render_scene_bvh_antialiased(const Scene&, const Camera&, int w, int h, int spp, int)
+ *     (Code/Render/Raytracer.h:65-67, defined Raytracer.cpp:612-621, called from Main.cpp:196-198),
+ * i.e. `Raytracer rt(scene); rt.render(camera, w, h, spp)` (Raytracer.h:27,33-34).  The entry points
+ * below are what a host implementation of that function binds: the host flattens its Scene into
+ * the plain arrays of mirt_scene_desc, hands them over once, and asks for frames.
+ *
+ * Conventions: plain C structs, no C++ types, no exceptions across the boundary.  Every function
+ * returns MIRT_OK (0) or a negative mirt_status and leaves a message for mirt_last_error() (kept per
+ * calling thread).  Calls block until the result is complete.  A mirt_scene handle owns all device
+ * memory it allocates and may be used by one thread at a time.  All floating-point data is IEEE
+ * double, exactly as in the reference (Code/Math/Vector.h:111-119).
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_ABI_VERSION 1
+
+typedef enum mirt_status {
+  MIRT_OK = 0,
+  MIRT_ERR_INVALID = -1,   /* bad argument or inconsistent scene description */
+  MIRT_ERR_DEVICE = -2,    /* HIP runtime error (no device, launch failure, ...) */
+  MIRT_ERR_MEMORY = -3,    /* host or device allocation failed */
+  MIRT_ERR_UNSUPPORTED = -4
+} mirt_status;
+
+/* Primitive kinds.  A primitive's index in mirt_scene_desc.prims IS its identity: the reference
+ * numbers objects spheres, cubes, planes, toruses, cylinders, cones in that order (Bvh.cpp:244-304,
+ * Raytracer.cpp:29-36) and the flattened array keeps that order. */
+enum { MIRT_SPHERE = 0, MIRT_CUBE = 1, MIRT_PLANE = 2, MIRT_TORUS = 3, MIRT_CYLINDER = 4, MIRT_CONE = 5 };
+
+/* One BVH node, 64 bytes (BVHNode, Bvh.h:18-27).  Nodes are stored in the depth-first order of
+ * the reference's recursion (intersect_bvh, Bvh.cpp:306-333: node, left subtree, right subtree), so
+ * the left child of inner node i is i + 1.  A leaf has left = right = -1 and names
+ * leaf_prims[first .. first + count); an inner node has count = 0. */
+typedef struct mirt_node {
+  double bmin[3];
+  double bmax[3];
+  int32_t left;
+  int32_t right;
+  int32_t first;
+  int32_t count;
+} mirt_node;
+
+/* One primitive (Shape, Shape.h:8-21, plus the per-kind fields of Sphere.h/Cube.h/Plane.h/Torus.h/
+ * Cylinder.h/Cone.h).  Matrices are row-major 4x4 (Mat4, Transform.h:12-13). */
+typedef struct mirt_prim {
+  int32_t type;       /* MIRT_SPHERE ... MIRT_CONE */
+  int32_t visible;    /* Shape::visible (Bvh.cpp:255-278) */
+  int32_t has_motion; /* Shape::has_motion */
+  int32_t material;   /* index into materials */
+  double o2w[16];     /* cached_transform.object_to_world (SceneLoader.cpp:868-889) */
+  double w2o[16];     /* cached_transform.world_to_object */
+  double m0[16];      /* start_transform (matrix_t0) */
+  double m1[16];      /* end_transform (matrix_t1) */
+  double param[4];    /* torus: major, minor radius; cylinder, cone: radius, depth; cube: scale x, y, z */
+  int32_t first_point; /* plane: range in plane_points (3 doubles per point) */
+  int32_t n_points;
+} mirt_prim;
+
+/* Material (Material.h:7-49), with texture names resolved to indices into `textures`.  An index is
+ * -1 when the name is empty or the image is not loaded (the reference loads the maps of spheres,
+ * cubes and planes only: Raytracer.cpp:94-108). */
+typedef struct mirt_material {
+  double diffuse[3];
+  double specular[3];
+  double ambient[3];
+  double emission[3];
+  double shininess;
+  double glossiness;
+  double reflectivity;
+  double transparency;
+  double refractive_index;
+  double emission_strength;
+  double bump_strength;
+  int32_t has_texture; /* Material::has_texture */
+  int32_t texture;     /* texture_file */
+  int32_t normal_map;
+  int32_t bump_map;
+} mirt_material;
+
+/* Light (Light.h:8-34).  Every kind shades as a point light at `location` (Raytracer.cpp:266-271);
+ * only AREA lights sample their surface for visibility (Light.h:38-69). */
+enum { MIRT_LIGHT_POINT = 0, MIRT_LIGHT_AREA = 1 };
+enum { MIRT_AREA_RECT = 0, MIRT_AREA_DISK = 1 }; /* SQUARE/RECTANGLE vs anything else (Light.h:59-68) */
+typedef struct mirt_light {
+  double location[3];
+  double color[3];
+  double normal[3];
+  double intensity;
+  double area_size[2];
+  int32_t type;
+  int32_t area_shape;
+  int32_t samples;
+  int32_t pad_;
+} mirt_light;
+
+/* Texture image (Image, Image.h:10-15): width * height RGB triples, row 0 first, as read from the
+ * PPM; a texel's value is rgb / max_value (Image.cpp:118-120). */
+typedef struct mirt_texture {
+  int32_t width;
+  int32_t height;
+  int32_t max_value;
+  int32_t pad_;
+  const uint16_t *rgb;
+} mirt_texture;
+
+typedef struct mirt_scene_desc {
+  int32_t n_nodes;
+  int32_t n_leaf_prims;
+  int32_t n_prims;
+  int32_t n_plane_points;
+  int32_t n_materials;
+  int32_t n_lights;
+  int32_t n_textures;
+  int32_t pad_;
+  const mirt_node *nodes;
+  const int32_t *leaf_prims;
+  const mirt_prim *prims;
+  const double *plane_points;
+  const mirt_material *materials;
+  const mirt_light *lights;
+  const mirt_texture *textures;
+  double background_color[3]; /* SceneSettings (Scene.h:18-19) */
+  double background_strength;
+} mirt_scene_desc;
+
+/* Camera (Camera.h:10-30), the fields Camera::get_ray reads (Camera.cpp:10-111). */
+typedef struct mirt_camera {
+  double location[3];
+  double gaze[3];
+  double up[3];
+  double focal_length;
+  double sensor_height;
+  double focus_distance;
+  double aperture_fstop;
+  int32_t dof_enabled;
+  int32_t pad_;
+} mirt_camera;
+
+enum { MIRT_TONEMAP_NONE = 0, MIRT_TONEMAP_REINHARD = 1, MIRT_TONEMAP_EXPOSURE = 2 };
+enum {
+  MIRT_SAMPLING_JITTER = 0, /* u = x + rnd, v = y + rnd, time = rnd or 0.5 (Raytracer.cpp:533-538) */
+  MIRT_SAMPLING_CENTRE = 1  /* u = x + 0.5, v = y + 0.5, time = 0.5: the deterministic parity mode */
+};
+
+/* Snapshot of the RenderConfig fields the render path reads (Config.h:11-168), plus the engine's
+ * own seed and sampling mode. */
+typedef struct mirt_config {
+  int32_t max_ray_depth;       /* Raytracer.cpp:297 */
+  int32_t shadow_samples;      /* Raytracer.cpp:146-149 */
+  int32_t glossy_samples;      /* Raytracer.cpp:331-337 */
+  int32_t enable_motion_blur;  /* Raytracer.cpp:538 */
+  int32_t enable_textures;     /* Raytracer.cpp:221,229,250,391 */
+  int32_t use_adaptive_epsilon;/* Raytracer.cpp:172,323,427 */
+  int32_t tone_mapping_mode;   /* Raytracer.cpp:547-559 */
+  int32_t enable_gamma_correction; /* Raytracer.cpp:563 */
+  double light_intensity_factor;   /* Raytracer.cpp:270 */
+  double ambient_factor;           /* Raytracer.cpp:258 */
+  double ray_offset_epsilon;       /* Raytracer.cpp:171,322,426 */
+  double adaptive_epsilon_scale;
+  double pure_glass_threshold;     /* Raytracer.cpp:307 */
+  double exposure;
+  double gamma;
+  uint64_t seed;      /* seed of the addressed random function (mirt_rng.h) */
+  int32_t sampling;   /* MIRT_SAMPLING_* */
+  int32_t pad_;
+} mirt_config;
+
+/* Counters and timings of one mirt_render* call. */
+typedef struct mirt_stats {
+  uint64_t primary_rays;     /* camera samples traced */
+  uint64_t secondary_rays;   /* reflection, glossy and refraction rays traced */
+  uint64_t shadow_segments;  /* closest-hit queries issued for shadows (Raytracer.cpp:181-203) */
+  uint64_t node_tests;       /* ray/box tests, counted per ray */
+  uint64_t prim_tests;       /* ray/primitive tests, counted per ray (g_intersection_tests, Bvh.cpp:246) */
+  uint64_t launches;         /* kernel launches */
+  double device_ms;          /* HIP-event time from first launch to last, on the engine's stream */
+  double trace_kernel_ms;    /* sum of HIP-event durations of the trace/shade launches */
+  uint64_t trace_kernel_launches;
+} mirt_stats;
+
+typedef struct mirt_scene mirt_scene;
+
+/* Number of HIP devices visible to the process, or a negative mirt_status. */
+int mirt_device_count(void);
+
+/* Fills *cfg with the defaults of RenderConfig (Config.h) and jittered sampling, seed 0. */
+void mirt_config_defaults(mirt_config *cfg);
+
+/* Validates `desc`, derives the engine's device layout from it and uploads it to HIP device
+ * `device`.  `desc` and everything it points to may be released after the call returns.
+ * Stands for `Raytracer::Raytracer(const Scene&)` (Raytracer.cpp:26-71) minus the BVH build, which
+ * the host does (it is part of `desc`). */
+int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out);
+void mirt_scene_destroy(mirt_scene *scene);
+
+/* Renders one frame; stands for `Raytracer::render` (Raytracer.cpp:475-607).
+ * rgb_out: caller-owned HOST buffer of height * width * 3 doubles, row-major, the post-gamma,
+ * un-clamped values the reference stores in Image.pixels (Raytracer.cpp:544-570).
+ * stats may be NULL. */
+int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
+                int height, int spp, double *rgb_out, mirt_stats *stats);
+
+/* The same frame, sharded for one-process-per-GPU rendering: the image is cut into tiles of
+ * tile_w x tile_h pixels numbered row-major, and this call renders the tiles t with
+ * t % world == rank.  d_rgb_out is a DEVICE pointer (on the scene's device) to
+ * mirt_tile_buffer_pixels(...) * 3 doubles: the owned tiles in increasing t, each tile stored
+ * row-major as tile_h rows of tile_w pixels (edge tiles are padded; padding is written as 0).
+ * With world == 1 and tile_w == width, tile_h == height this is the whole frame, row-major.
+ * `stream` is a hipStream_t (NULL: the engine's own stream); the call synchronises it before
+ * returning.  No counterpart in the reference (it has one address space). */
+int mirt_render_tiles(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
+                      int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
+                      double *d_rgb_out, void *stream, mirt_stats *stats);
+int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int tile_h, int rank, int world);
+
+/* Parity hook: closest hit of the camera ray through every pixel centre at time 0.5, i.e.
+ * `intersect_bvh(camera.get_ray(x+.5, y+.5, w, h, .5), root, scene, hit, 1e-5, DBL_MAX)`
+ * (Bvh.cpp:306, called as in Raytracer.cpp:303).  Host buffers of width*height entries;
+ * prim_id is -1 on a miss; t, normal (3 per pixel, face-forwarded unit normal) and uv (2 per pixel)
+ * may each be NULL. */
+int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int width, int height,
+                   int32_t *prim_id, double *t, double *normal, double *uv);
+
+const char *mirt_last_error(void);
+int mirt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  Generates tests/golden/*.npz by running oracle/_ref/ref_harness, i.e. the
+reference renderer itself (built in place by oracle/Makefile), on the bundled scenes.
+
+Run in the build container (needs /root/reference to have built oracle/_ref):
+    make -C oracle ref && python oracle/make_goldens.py
+The outputs are plain numeric arrays (numpy.load(..., allow_pickle=False) reads them).
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+FIX = os.path.join(ROOT, "fixtures")
+OUT = os.path.join(ROOT, "tests", "golden")
+SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene"]
+W, H = 96, 54  # deterministic (pixel-centre) maps
+
+# stochastic renders: (name, scene, w, h, spp, harness flags); tests/golden_cases.py maps the flags
+# to mirt_config fields
+RENDERS = [
+    ("t5_default", "Test5", 64, 36, 4, ["--max-depth", "5"]),
+    ("t5_glossy", "Test5", 64, 36, 2, ["--max-depth", "8", "--glossy", "8", "--shadow-samples", "16"]),
+    ("t7_dof_soft", "Test7", 48, 27, 2, ["--max-depth", "8", "--glossy", "4", "--dof", "0.95", "16.12"]),
+    ("t6_soft9", "Test6", 48, 27, 2, ["--max-depth", "4", "--shadow-samples", "9"]),
+    ("t2_texture", "Test2", 64, 36, 2, ["--max-depth", "4"]),
+    ("t3_bump", "Test3", 64, 36, 2, ["--max-depth", "4"]),
+    ("t4_glossy3", "Test4", 64, 36, 2, ["--max-depth", "6", "--glossy", "3"]),
+    ("t1_cfg0", "Test1", 80, 60, 1, ["--max-depth", "3"]),
+    ("t5_nomb_seed7", "Test5", 64, 36, 2, ["--max-depth", "5", "--motion-blur", "0", "--seed", "7"]),
+]
+
+
+def harness(*args):
+    r = subprocess.run([HARNESS, "--root", FIX, *args], check=True, capture_output=True)
+    return r.stdout, r.stderr.decode()
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` where /root/reference exists")
+    os.makedirs(OUT, exist_ok=True)
+    n = W * H
+    dumps = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for s in SCENES:
+            scene = f"ASCII/{s}.txt"
+            dumps[f"{s}_scene"] = np.frombuffer(harness("dump-scene", scene)[0], dtype=np.uint8)
+            dumps[f"{s}_bvh"] = np.frombuffer(harness("dump-bvh", scene)[0], dtype=np.uint8)
+            out = os.path.join(tmp, "h.bin")
+            harness("hits", scene, str(W), str(H), out)
+            raw = np.fromfile(out, dtype=np.uint8)
+            ids = raw[: 4 * n].view(np.int32)
+            front = raw[4 * n: 8 * n].view(np.int32)
+            rest = raw[8 * n:].view(np.float64)
+            harness("trace", scene, str(W), str(H), out, "--max-depth", "5", "--motion-blur", "0")
+            rgb = np.fromfile(out, dtype=np.float64)
+            np.savez_compressed(
+                os.path.join(OUT, f"hits_{s}.npz"), width=W, height=H, prim_id=ids, front=front, t=rest[:n],
+                normal=rest[n: 4 * n].reshape(n, 3), point=rest[4 * n: 7 * n].reshape(n, 3),
+                uv=rest[7 * n: 9 * n].reshape(n, 2), trace_rgb_depth5=rgb.reshape(n, 3))
+            print(s, "hit fraction", float((ids >= 0).mean()))
+        for name, s, w, h, spp, flags in RENDERS:
+            out = os.path.join(tmp, "r.bin")
+            _, err = harness("render", f"ASCII/{s}.txt", str(w), str(h), str(spp), out, *flags)
+            prim_tests = int(err.split()[1])
+            rgb = np.fromfile(out, dtype=np.float64).reshape(h * w, 3)
+            np.savez_compressed(os.path.join(OUT, f"render_{name}.npz"), width=w, height=h, spp=spp, rgb=rgb,
+                                prim_tests=prim_tests)
+            print(name, "mean", float(rgb.mean()), "prim_tests", prim_tests)
+    np.savez_compressed(os.path.join(OUT, "dumps.npz"), **dumps)
+
+
+if __name__ == "__main__":
+    main()
