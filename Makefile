@@ -20,7 +20,7 @@ HOST_SRCS := $(HOST)/mirt_math.cpp $(HOST)/scene_loader.cpp $(HOST)/image_io.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.h) include/mirt.h
 
 HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function \
-            -ffp-contract=on $(EXTRA_HIPFLAGS)
+            -ffp-contract=on -munsafe-fp-atomics -fvisibility=hidden $(EXTRA_HIPFLAGS)
 # no FMA contraction on the host: the matrices and boxes computed here are compared bit for bit
 # with the reference's
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra -Iinclude -I$(HOST)
@@ -35,8 +35,21 @@ cli: $(BIN)/raytracer
 $(LIB) $(BIN):
 	mkdir -p $@
 
-$(LIB)/libmirt.so: $(ENGINE_SRCS) $(ENGINE_HDRS) | $(LIB)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINE_SRCS)
+# device code by hipcc; the engine's host side by the host compiler without FMA contraction, with
+# hidden visibility so that only the C ABI is exported
+ENGINE_HOSTFLAGS := $(HOSTFLAGS) -fvisibility=hidden -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$(CSRC)
+BUILD := $(LIB)/obj
+
+$(BUILD): | $(LIB)
+	mkdir -p $@
+$(BUILD)/kernels.o: $(CSRC)/kernels.hip $(ENGINE_HDRS) | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(BUILD)/engine.o: $(CSRC)/engine.cpp $(ENGINE_HDRS) $(HOST)/mirt_math.h | $(BUILD)
+	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
+$(BUILD)/engine_math.o: $(HOST)/mirt_math.cpp $(HOST)/mirt_math.h | $(BUILD)
+	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
+$(LIB)/libmirt.so: $(BUILD)/kernels.o $(BUILD)/engine.o $(BUILD)/engine_math.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 $(LIB)/libmirt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIB)/libmirt.so | $(LIB)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -L$(LIB) -lmirt -Wl,-rpath,'$$ORIGIN'

@@ -185,7 +185,9 @@ typedef struct mirt_stats {
   uint64_t launches;         /* kernel launches */
   double device_ms;          /* HIP-event time from first launch to last, on the engine's stream */
   double trace_kernel_ms;    /* sum of HIP-event durations of the trace/shade launches */
+  double shadow_kernel_ms;   /* sum of HIP-event durations of the shadow launches */
   uint64_t trace_kernel_launches;
+  uint64_t shadow_kernel_launches;
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene;

@@ -77,7 +77,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("secondary_rays", C.c_uint64), ("shadow_segments", C.c_uint64),
                 ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("launches", C.c_uint64),
-                ("device_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("trace_kernel_launches", C.c_uint64)]
+                ("device_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
+                ("trace_kernel_launches", C.c_uint64), ("shadow_kernel_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,0 +1,183 @@
+"""Python face of the drop-in path: parse a scene with the host library, hand it to the HIP engine
+through the C ABI (include/mirt.h), get frames back as numpy arrays.
+
+There is no CPU rendering path here: every render call goes to libmirt.so and fails loudly when
+the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+
+
+class MirtError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = A.engine_lib().mirt_last_error()
+        raise MirtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def default_config(**overrides):
+    """RenderConfig defaults of the reference (Code/Core/Config.h), as a mirt_config."""
+    cfg = A.Config()
+    A.engine_lib().mirt_config_defaults(C.byref(cfg))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(f"mirt_config has no field {k!r}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+class HostScene:
+    """A parsed + flattened scene (load_scene + BVH build + texture preload, all on the host)."""
+
+    def __init__(self, path, texture_root=None):
+        lib = A.host_lib()
+        if texture_root is None:
+            # scenes live in <root>/ASCII/, textures in <root>/Textures/ (the reference's layout)
+            texture_root = os.path.dirname(os.path.dirname(os.path.abspath(path)))
+        self._lib = lib
+        self._h = lib.mirt_host_scene_load(os.fsencode(path), os.fsencode(texture_root))
+        if not self._h:
+            raise MemoryError("mirt_host_scene_load")
+        self.path = path
+        self.desc = A.SceneDesc()
+        lib.mirt_host_scene_desc(self._h, C.byref(self.desc))
+
+    def close(self):
+        if self._h:
+            self._lib.mirt_host_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def camera_count(self):
+        return self._lib.mirt_host_scene_camera_count(self._h)
+
+    def camera(self, index=0, dof=None):
+        """Camera `index`; dof=None keeps the file's setting, dof=(fstop, focus) is --depth-of-field,
+        dof=False is --disable-dof (Main.cpp:160-176).  Returns (mirt_camera, (res_x, res_y))."""
+        cam, rx, ry = A.Camera(), C.c_int(), C.c_int()
+        if dof is None:
+            mode, f, d = 0, 0.0, 0.0
+        elif dof is False:
+            mode, f, d = 2, 0.0, 0.0
+        else:
+            mode, (f, d) = 1, dof
+        if self._lib.mirt_host_scene_camera(self._h, index, mode, f, d, C.byref(cam), C.byref(rx), C.byref(ry)) != 0:
+            raise IndexError(f"scene has no camera {index}")
+        return cam, (rx.value, ry.value)
+
+    def bvh_stats(self):
+        n, l, d = C.c_int(), C.c_int(), C.c_int()
+        self._lib.mirt_host_bvh_stats(self._h, C.byref(n), C.byref(l), C.byref(d))
+        return {"nodes": n.value, "leaves": l.value, "depth": d.value}
+
+    def dump_scene(self, path):
+        return self._lib.mirt_host_scene_dump(self._h, os.fsencode(path))
+
+    def dump_bvh(self, path):
+        return self._lib.mirt_host_bvh_dump(self._h, os.fsencode(path))
+
+
+class DeviceScene:
+    """A scene resident on one GPU (mirt_scene_create)."""
+
+    def __init__(self, scene, device=0):
+        self._lib = A.engine_lib()
+        self._h = C.c_void_p()
+        desc = scene.desc if isinstance(scene, HostScene) else scene
+        self._keep = scene  # the description's arrays must outlive the call only, but keep it simple
+        _check(self._lib.mirt_scene_create(C.byref(desc), device, C.byref(self._h)), "mirt_scene_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.mirt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera, config, width, height, spp):
+        """One frame: (height, width, 3) float64 array of post-gamma un-clamped values, and stats."""
+        out = np.empty((height, width, 3), dtype=np.float64)
+        st = A.Stats()
+        _check(self._lib.mirt_render(self._h, C.byref(camera), C.byref(config), width, height, spp,
+                                     out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)), "mirt_render")
+        return out, st.as_dict()
+
+    def render_tiles(self, camera, config, width, height, spp, tile_w, tile_h, rank, world, out_ptr, stream=None):
+        """This rank's tiles into the device buffer at `out_ptr` (see mirt_render_tiles)."""
+        st = A.Stats()
+        _check(self._lib.mirt_render_tiles(self._h, C.byref(camera), C.byref(config), width, height, spp, tile_w,
+                                           tile_h, rank, world, C.c_void_p(out_ptr), C.c_void_p(stream or 0),
+                                           C.byref(st)), "mirt_render_tiles")
+        return st.as_dict()
+
+    def trace_ids(self, camera, width, height):
+        n = width * height
+        ids = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float64)
+        nrm = np.empty((n, 3), dtype=np.float64)
+        uv = np.empty((n, 2), dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _check(self._lib.mirt_trace_ids(self._h, C.byref(camera), width, height,
+                                        ids.ctypes.data_as(C.POINTER(C.c_int32)), t.ctypes.data_as(dp),
+                                        nrm.ctypes.data_as(dp), uv.ctypes.data_as(dp)), "mirt_trace_ids")
+        return {"prim_id": ids, "t": t, "normal": nrm, "uv": uv}
+
+
+def tile_buffer_pixels(width, height, tile_w, tile_h, rank, world):
+    return int(A.engine_lib().mirt_tile_buffer_pixels(width, height, tile_w, tile_h, rank, world))
+
+
+def owned_tiles(width, height, tile_w, tile_h, rank, world):
+    """Tile indices (row-major) rendered by `rank`, in buffer order."""
+    tiles_x = (width + tile_w - 1) // tile_w
+    tiles_y = (height + tile_h - 1) // tile_h
+    return list(range(rank, tiles_x * tiles_y, world))
+
+
+def scatter_tiles(frame, buf, width, height, tile_w, tile_h, rank, world):
+    """Copies rank's compact tile buffer `buf` ((n_tiles*tile_h*tile_w, 3)) into the (H, W, 3) frame."""
+    tiles_x = (width + tile_w - 1) // tile_w
+    buf = buf.reshape(-1, tile_h, tile_w, 3)
+    for slot, t in enumerate(owned_tiles(width, height, tile_w, tile_h, rank, world)):
+        tx, ty = t % tiles_x, t // tiles_x
+        x0, y0 = tx * tile_w, ty * tile_h
+        w, h = min(tile_w, width - x0), min(tile_h, height - y0)
+        frame[y0:y0 + h, x0:x0 + w] = buf[slot, :h, :w]
+    return frame
+
+
+def write_ppm(path, rgb, binary=False):
+    """Writes an (H, W, 3) float64 frame as the reference writes its output (ASCII P3 by default)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w, _ = rgb.shape
+    A.host_lib().mirt_host_write_ppm(os.fsencode(path), rgb.ctypes.data_as(C.POINTER(C.c_double)), w, h,
+                                     1 if binary else 0)
+
+
+def read_ppm(path):
+    w, h, m = C.c_int(), C.c_int(), C.c_int()
+    lib = A.host_lib()
+    if lib.mirt_host_read_ppm(os.fsencode(path), C.byref(w), C.byref(h), C.byref(m), None) != 0:
+        raise IOError(f"cannot read PPM {path}")
+    out = np.empty((h.value, w.value, 3), dtype=np.float64)
+    lib.mirt_host_read_ppm(os.fsencode(path), C.byref(w), C.byref(h), C.byref(m),
+                           out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out, m.value

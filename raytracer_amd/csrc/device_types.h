@@ -1,0 +1,186 @@
+// Device-side data layout of the engine (HBM-resident, read-only during a frame) and the records
+// that flow between kernels.  Everything is IEEE double, as in the reference renderer.
+//
+//   DNode    64 B   BVH node in depth-first order with a skip link (index of the first node after
+//                   this node's subtree): the reference's fixed left-then-right recursion
+//                   (Code/Geometry/Bvh.cpp:306-333) becomes a stack-free walk  i -> i+1 | skip[i].
+//   DPrim   256 B   one primitive: kind, flags, the static object<->world maps (for a moving
+//                   primitive: the maps at shutter time 0.5, which is the time of every shadow ray,
+//                   Code/Core/Ray.h:15, and of every ray when motion blur is off) and the shape
+//                   parameters.  Planes keep their pre-computed plane equation in the same slots.
+//   DMotion 384 B   motion-blur data of a moving primitive: the TRS decomposition of matrix_t0 /
+//                   matrix_t1 done once on the host (Code/Math/Transform.cpp:145-206), so that a ray
+//                   only lerps, slerps and composes (Transform.cpp:239-256).
+#pragma once
+
+#include <stdint.h>
+
+#include "mirt.h"
+
+enum : int32_t { MOTION_NONE = 0, MOTION_TRANSLATE = 1, MOTION_GENERAL = 2 };
+
+struct alignas(64) DNode {
+  double bmin[3];
+  double bmax[3];
+  int32_t skip;   // next node in depth-first order after this subtree
+  int32_t first;  // leaf: first entry in leaf_prims; inner node: -1
+  int32_t count;  // leaf: number of primitives
+  int32_t pad;
+};
+static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte record");
+
+struct alignas(64) DPrim {
+  int32_t type;
+  int32_t visible;
+  int32_t motion;    // MOTION_*
+  int32_t material;
+  int32_t motion_index;  // into DScene::motion
+  int32_t plane_flags;   // plane: bit a set when extent along axis a exceeds the 1e-6 tolerance
+  int32_t pad0, pad1;
+  // transformed kinds: xf[0..11] = world_to_object rows 0-2 (3x4), xf[12..23] = object_to_world
+  // plane: xf[0..2] first point, [3..5] unit normal, [6..8] min corner, [9..11] max corner,
+  //        [12..14] unit edge 1, [15] |edge 1|, [16..18] unit edge 2, [19] |edge 2|
+  double xf[24];
+  double param[4];
+};
+static_assert(sizeof(DPrim) == 256, "DPrim must be 256 bytes");
+
+struct alignas(64) DMotion {
+  double t0[3], dt[3];  // translation at t=0 and its change over the shutter
+  double s0[3], ds[3];  // scale likewise
+  double q0[4], dq[4];  // unit start quaternion (w,x,y,z); end - start (lerp path) or the end quaternion (slerp path)
+  double dot;           // cosine between the two (after the shorter-arc sign flip)
+  double theta0;        // acos(dot)
+  double inv_sin0;      // 1 / sin(theta0)
+  int32_t lerp;         // dot > 0.9995: normalised lerp (Quaternion.h:88-96), else slerp
+  int32_t pad;
+  // MOTION_TRANSLATE only: constant rotation*scale block (row-major 3x3) and its inverse
+  double m[9];
+  double minv[9];
+};
+static_assert(sizeof(DMotion) == 384, "DMotion layout");
+
+struct DTexture {
+  const uint16_t *rgb;
+  int32_t width, height;
+  double inv_max;  // not used for the value itself (division is kept), only as a presence marker
+  int32_t max_value, pad;
+};
+
+struct DScene {
+  const DNode *nodes;
+  const int32_t *leaf_prims;
+  const DPrim *prims;
+  const DMotion *motion;
+  const mirt_material *materials;
+  const double *prim_transparency;  // materials[prims[i].material].transparency, for shadow rays
+  const mirt_light *lights;
+  const DTexture *textures;
+  int32_t n_nodes, n_prims, n_lights, n_textures;
+  double background[3];  // background_color * background_strength (Raytracer.cpp:472)
+  int32_t any_motion;    // some primitive has motion data
+  int32_t any_maps;      // some material samples a texture, normal map or bump map
+  int32_t max_children;  // most rays one hit can spawn, given the materials (and glossy_samples, added per frame)
+  int32_t pad;
+};
+
+// Camera with the basis of Camera::get_ray (Camera.cpp:32-58) evaluated once on the host.
+struct DCamera {
+  double location[3];
+  double gaze[3];  // as parsed, un-normalised (used by the focus-plane formula, Camera.cpp:83)
+  double w[3], u[3], v[3];
+  double viewport_w, viewport_h, image_plane_dist;
+  double focus_distance, aperture_radius;
+  int32_t dof;
+  int32_t pad;
+};
+
+// Per-frame constants.
+struct DFrame {
+  DCamera cam;
+  mirt_config cfg;
+  int32_t width, height, spp;
+  int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world;
+  int32_t blocks_x, blocks_y;  // 16x16-pixel thread blocks per tile
+  int32_t n_slots;             // tiles owned by this rank
+  const struct DLightFrame *light_frame;  // per light, per frame (depends on cfg.shadow_samples)
+};
+
+// Shadow sampling of one light for this frame (Raytracer.cpp:146-158).
+struct DLightFrame {
+  uint32_t dim;   // first random dimension of this light's strata (mirt_rng.h, MIRT_DIM_SHADOW)
+  int32_t side;   // floor(sqrt(samples)), at least 1; side*side strata are taken
+  double inv_n;   // 1 / (side*side)
+};
+
+// Ray queue, structure of arrays; one queue per ray-tree depth.
+struct DRayQueue {
+  double *ox, *oy, *oz, *dx, *dy, *dz, *time, *wr, *wg, *wb;
+  uint64_t *key;
+  uint32_t *pixel;
+  uint32_t *count;  // device counter
+  uint32_t capacity;
+};
+
+// Shadow work item: one (hit, light) pair; 64 bytes.
+struct alignas(16) DShadowItem {
+  double p[3];   // shaded point
+  double c[3];   // unshadowed contribution of this light to the pixel, already divided by the strata count
+  uint64_t key;  // random key of the ray-tree node that owns the hit
+  uint32_t pixel;
+  uint32_t light;
+};
+static_assert(sizeof(DShadowItem) == 64, "DShadowItem must be 64 bytes");
+
+struct DCounters {
+  unsigned long long primary, secondary, shadow_segments, node_tests, prim_tests;
+};
+
+// ---- kernel argument blocks (passed by value) --------------------------------------------------
+struct TraceArgs {
+  DScene sc;
+  DFrame fr;
+  DRayQueue in;       // unused by the primary launch
+  DRayQueue out;
+  DShadowItem *shadow;
+  uint32_t *shadow_count;
+  uint32_t shadow_capacity;
+  double *accum;      // 3 doubles per pixel of this rank's tile buffer
+  DCounters *counters;
+  uint32_t first;     // PRIMARY: first 16x16 block of this launch; else first queue entry
+  uint32_t n;         // PRIMARY: number of blocks; else number of queue entries
+  int32_t depth;      // depth of the rays this launch traces
+};
+
+struct ShadowArgs {
+  DScene sc;
+  DFrame fr;
+  const DShadowItem *items;
+  uint32_t n;
+  double *accum;
+  DCounters *counters;
+};
+
+struct ResolveArgs {
+  const double *accum;
+  double *out;
+  uint32_t n_pixels;
+  int32_t spp;
+  mirt_config cfg;
+};
+
+struct IdsArgs {
+  DScene sc;
+  DCamera cam;
+  int32_t width, height;
+  int32_t *prim_id;
+  double *t, *normal, *uv;
+};
+
+// Launchers defined in kernels.hip (the only translation unit compiled for the GPU).
+// uv: the scene samples image maps, so hits carry texture coordinates and a tangent frame;
+// motion: some ray of the launch may be at a shutter time other than 0.5.
+void launch_trace(bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
+void launch_shadow(unsigned grid, void *stream, const ShadowArgs &a);
+void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a);
+void launch_trace_ids(unsigned grid, void *stream, const IdsArgs &a);

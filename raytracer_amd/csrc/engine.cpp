@@ -1,0 +1,815 @@
+// Host side of the engine: the C ABI of include/mirt.h.  Derives the device layout from a
+// mirt_scene_desc, owns the device memory, and drives the per-depth kernel pipeline of pipeline.h.
+// Compiled as plain C++ (no FMA contraction: the matrices prepared here are the same numbers the
+// reference computes); the kernels are reached through the launchers of kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../host/mirt_math.h"
+#include "device_types.h"
+#include "mirt.h"
+#include "mirt_rng.h"
+
+#define MIRT_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(e_ == hipErrorOutOfMemory ? MIRT_ERR_MEMORY : MIRT_ERR_DEVICE, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                          \
+  } while (0)
+
+struct DeviceBuffer {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DeviceBuffer() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t reserve(size_t n) {  // grow-only
+    if (n <= bytes) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+template <class T> hipError_t upload(DeviceBuffer &b, const std::vector<T> &v) {
+  hipError_t e = b.reserve(std::max<size_t>(v.size() * sizeof(T), 16));
+  if (e != hipSuccess || v.empty()) return e;
+  return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+struct RayQueueMem {
+  DeviceBuffer mem;
+  DRayQueue q{};
+};
+
+// which kinds of ray-spawning materials the scene has (decides the most children one hit can have)
+struct SpawnKinds {
+  bool mirror = false, lobe = false, glass = false, mirror_glass = false, lobe_glass = false;
+};
+
+}  // namespace
+
+struct mirt_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DScene d{};
+  DeviceBuffer nodes, leaf_prims, prims, motion, materials, transparency, lights, textures, light_frame;
+  std::vector<DeviceBuffer> texels;
+  std::vector<mirt_light> host_lights;
+  SpawnKinds kinds;
+  // per-frame working memory, grown on demand and kept
+  std::vector<RayQueueMem> queues;  // index = depth of the rays it holds
+  DeviceBuffer shadow_items, counters, accum, out, ids;
+  uint32_t *pinned = nullptr;  // [0] ray count, [1] shadow count
+  uint32_t *shadow_count = nullptr;
+  size_t ray_capacity = 0, shadow_capacity = 0;
+  std::vector<hipEvent_t> events;
+  ~mirt_scene() {
+    for (auto e : events) (void)hipEventDestroy(e);
+    if (pinned) (void)hipHostFree(pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+Mat4 mat_of(const double *a) {
+  Mat4 m;
+  std::memcpy(m.m, a, sizeof(double) * 16);
+  return m;
+}
+
+void store_3x4(double *dst, const Mat4 &m) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) dst[r * 4 + c] = m.m[r][c];
+}
+
+int validate(const mirt_scene_desc *s) {
+  if (!s) return fail(MIRT_ERR_INVALID, "scene description is NULL");
+  if (s->n_nodes < 1 || !s->nodes) return fail(MIRT_ERR_INVALID, "scene needs at least one BVH node");
+  if (s->n_prims < 0 || s->n_leaf_prims < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_textures < 0 ||
+      s->n_plane_points < 0)
+    return fail(MIRT_ERR_INVALID, "negative count in scene description");
+  if ((s->n_prims && !s->prims) || (s->n_leaf_prims && !s->leaf_prims) || (s->n_materials && !s->materials) ||
+      (s->n_lights && !s->lights) || (s->n_textures && !s->textures) || (s->n_plane_points && !s->plane_points))
+    return fail(MIRT_ERR_INVALID, "NULL array with a non-zero count");
+  for (int i = 0; i < s->n_nodes; ++i) {
+    const mirt_node &n = s->nodes[i];
+    if (n.left < 0) {
+      if (n.count < 0 || n.first < 0 || (long long)n.first + n.count > s->n_leaf_prims)
+        return fail(MIRT_ERR_INVALID, "leaf node %d names leaf_prims[%d..%d) outside [0,%d)", i, n.first,
+                    n.first + n.count, s->n_leaf_prims);
+    } else if (n.left != i + 1 || n.right <= n.left || n.right >= s->n_nodes) {
+      return fail(MIRT_ERR_INVALID, "inner node %d: children (%d,%d) are not in depth-first order", i, n.left,
+                  n.right);
+    }
+  }
+  for (int i = 0; i < s->n_leaf_prims; ++i)
+    if (s->leaf_prims[i] < 0 || s->leaf_prims[i] >= s->n_prims)
+      return fail(MIRT_ERR_INVALID, "leaf_prims[%d] = %d is not a primitive", i, s->leaf_prims[i]);
+  for (int i = 0; i < s->n_prims; ++i) {
+    const mirt_prim &p = s->prims[i];
+    if (p.type < MIRT_SPHERE || p.type > MIRT_CONE) return fail(MIRT_ERR_INVALID, "primitive %d: unknown type %d", i, p.type);
+    if (p.material < 0 || p.material >= s->n_materials)
+      return fail(MIRT_ERR_INVALID, "primitive %d: material %d out of range", i, p.material);
+    if (p.type == MIRT_PLANE && (p.n_points < 0 || p.first_point < 0 ||
+                                 (long long)p.first_point + p.n_points > s->n_plane_points))
+      return fail(MIRT_ERR_INVALID, "plane %d: points out of range", i);
+  }
+  for (int i = 0; i < s->n_materials; ++i) {
+    const mirt_material &m = s->materials[i];
+    const int idx[3] = {m.texture, m.normal_map, m.bump_map};
+    for (int k : idx)
+      if (k < -1 || k >= s->n_textures) return fail(MIRT_ERR_INVALID, "material %d: texture index %d out of range", i, k);
+  }
+  for (int i = 0; i < s->n_textures; ++i) {
+    const mirt_texture &t = s->textures[i];
+    if (t.width <= 0 || t.height <= 0 || t.max_value <= 0 || !t.rgb)
+      return fail(MIRT_ERR_INVALID, "texture %d is empty", i);
+  }
+  return MIRT_OK;
+}
+
+// index of the first node after the subtree of node i (nodes are in depth-first order)
+int fill_skip(const mirt_scene_desc &s, std::vector<DNode> &out, int i) {
+  const mirt_node &n = s.nodes[i];
+  DNode &d = out[i];
+  for (int a = 0; a < 3; ++a) {
+    d.bmin[a] = n.bmin[a];
+    d.bmax[a] = n.bmax[a];
+  }
+  d.pad = 0;
+  int next;
+  if (n.left < 0) {
+    d.first = n.first;
+    d.count = n.count;
+    next = i + 1;
+  } else {
+    d.first = -1;
+    d.count = 0;
+    const int after_left = fill_skip(s, out, n.left);
+    if (after_left != n.right) return -1;
+    next = fill_skip(s, out, n.right);
+    if (next < 0) return -1;
+  }
+  out[i].skip = next;
+  return next;
+}
+
+// Plane.cpp:15-19, :46-56, :106-113 evaluated once.
+void prepare_plane(const mirt_scene_desc &s, const mirt_prim &p, DPrim &d) {
+  if (p.n_points < 3) {  // Plane.cpp:11-13: never hit
+    d.visible = 0;
+    return;
+  }
+  const double *pts = s.plane_points + 3 * (size_t)p.first_point;
+  const Vec3 p0(pts[0], pts[1], pts[2]), p1(pts[3], pts[4], pts[5]), p2(pts[6], pts[7], pts[8]);
+  const Vec3 e1 = p1 - p0, e2 = p2 - p0;
+  const Vec3 n = e1.cross(e2).norm();
+  Vec3 lo = p0, hi = p0;
+  for (int i = 0; i < p.n_points; ++i) {
+    const Vec3 q(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    lo.x = std::min(lo.x, q.x); lo.y = std::min(lo.y, q.y); lo.z = std::min(lo.z, q.z);
+    hi.x = std::max(hi.x, q.x); hi.y = std::max(hi.y, q.y); hi.z = std::max(hi.z, q.z);
+  }
+  const double tol = 1e-6;
+  d.plane_flags = (hi.x - lo.x > tol ? 1 : 0) | (hi.y - lo.y > tol ? 2 : 0) | (hi.z - lo.z > tol ? 4 : 0);
+  const double l1 = e1.length(), l2 = e2.length();
+  const Vec3 e1n = e1 / l1, e2n = e2 / l2;
+  const double v[20] = {p0.x, p0.y, p0.z, n.x, n.y, n.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z,
+                        e1n.x, e1n.y, e1n.z, l1, e2n.x, e2n.y, e2n.z, l2};
+  std::memcpy(d.xf, v, sizeof v);
+}
+
+// Decomposition half of Mat4::interpolate (Transform.cpp:239-247) and the t-independent part of
+// Quaternion::slerp (Quaternion.h:73-105).
+void prepare_motion(const mirt_prim &p, DPrim &d, std::vector<DMotion> &motion) {
+  const Mat4 a = mat_of(p.m0), b = mat_of(p.m1);
+  DMotion mo;
+  std::memset(&mo, 0, sizeof mo);
+  const Vec3 ta = a.extract_translation(), tb = b.extract_translation();
+  const Vec3 sa = a.extract_scale(), sb = b.extract_scale();
+  const Quaternion q0 = a.extract_rotation().norm();
+  Quaternion q1 = b.extract_rotation().norm();
+  double dot = q0.dot(q1);
+  if (dot < 0.0) {
+    q1 = Quaternion(-q1.w, -q1.x, -q1.y, -q1.z);
+    dot = -dot;
+  }
+  const Vec3 dt = tb - ta, ds = sb - sa;
+  const double t0[3] = {ta.x, ta.y, ta.z}, dtt[3] = {dt.x, dt.y, dt.z};
+  const double s0[3] = {sa.x, sa.y, sa.z}, dss[3] = {ds.x, ds.y, ds.z};
+  std::memcpy(mo.t0, t0, sizeof t0);
+  std::memcpy(mo.dt, dtt, sizeof dtt);
+  std::memcpy(mo.s0, s0, sizeof s0);
+  std::memcpy(mo.ds, dss, sizeof dss);
+  mo.q0[0] = q0.w; mo.q0[1] = q0.x; mo.q0[2] = q0.y; mo.q0[3] = q0.z;
+  mo.lerp = dot > 0.9995 ? 1 : 0;
+  if (mo.lerp) {
+    mo.dq[0] = q1.w - q0.w; mo.dq[1] = q1.x - q0.x; mo.dq[2] = q1.y - q0.y; mo.dq[3] = q1.z - q0.z;
+  } else {
+    mo.dq[0] = q1.w; mo.dq[1] = q1.x; mo.dq[2] = q1.y; mo.dq[3] = q1.z;
+    dot = std::min(1.0, std::max(-1.0, dot));
+    mo.theta0 = std::acos(dot);
+    mo.inv_sin0 = 1.0 / std::sin(mo.theta0);
+  }
+  mo.dot = dot;
+  const bool fixed_rs = mo.lerp && mo.dq[0] == 0.0 && mo.dq[1] == 0.0 && mo.dq[2] == 0.0 && mo.dq[3] == 0.0 &&
+                        ds.x == 0.0 && ds.y == 0.0 && ds.z == 0.0;
+  if (fixed_rs) {
+    // rotation and scale do not change over the shutter: only the translation is interpolated
+    const Mat4 rs = Mat4::compose(Vec3(0, 0, 0), q0.norm(), sa);
+    const Mat4 inv = rs.inverse();
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        mo.m[r * 3 + c] = rs.m[r][c];
+        mo.minv[r * 3 + c] = inv.m[r][c];
+      }
+    d.motion = MOTION_TRANSLATE;
+  } else {
+    d.motion = MOTION_GENERAL;
+  }
+  d.motion_index = (int32_t)motion.size();
+  motion.push_back(mo);
+}
+
+SpawnKinds spawn_kinds(const mirt_scene_desc &s) {
+  SpawnKinds k;
+  for (int i = 0; i < s.n_materials; ++i) {
+    const mirt_material &m = s.materials[i];
+    const bool refl = m.reflectivity > 0.0, glass = m.transparency > 0.0, lobe = refl && m.glossiness < 0.94;
+    if (refl && !lobe && !glass) k.mirror = true;
+    if (lobe && !glass) k.lobe = true;
+    if (glass && !refl) k.glass = true;
+    if (refl && !lobe && glass) k.mirror_glass = true;
+    if (lobe && glass) k.lobe_glass = true;
+  }
+  return k;
+}
+
+int max_children(const SpawnKinds &k, int glossy_samples) {
+  const int g = glossy_samples > 1 ? glossy_samples : 1;
+  int m = 1;
+  if (k.mirror) m = std::max(m, 1);
+  if (k.lobe) m = std::max(m, g);
+  if (k.glass) m = std::max(m, 2);
+  if (k.mirror_glass) m = std::max(m, 3);
+  if (k.lobe_glass) m = std::max(m, g + 2);
+  return m;
+}
+
+hipError_t ensure_queue(mirt_scene *sc, size_t depth) {
+  if (sc->queues.size() <= depth) sc->queues.resize(depth + 1);
+  RayQueueMem &rq = sc->queues[depth];
+  const size_t cap = sc->ray_capacity;
+  if (rq.q.capacity == cap && rq.mem.p) return hipSuccess;
+  const size_t bytes = cap * (10 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t)) + 256;
+  hipError_t e = rq.mem.reserve(bytes);
+  if (e != hipSuccess) return e;
+  char *p = rq.mem.as<char>();
+  double **fields[10] = {&rq.q.ox, &rq.q.oy, &rq.q.oz, &rq.q.dx, &rq.q.dy, &rq.q.dz, &rq.q.time, &rq.q.wr, &rq.q.wg, &rq.q.wb};
+  for (auto f : fields) {
+    *f = reinterpret_cast<double *>(p);
+    p += cap * sizeof(double);
+  }
+  rq.q.key = reinterpret_cast<uint64_t *>(p);
+  p += cap * sizeof(uint64_t);
+  rq.q.pixel = reinterpret_cast<uint32_t *>(p);
+  p += cap * sizeof(uint32_t);
+  rq.q.count = reinterpret_cast<uint32_t *>(p);
+  rq.q.capacity = (uint32_t)cap;
+  return hipSuccess;
+}
+
+size_t env_size(const char *name, size_t dflt) {
+  const char *v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  const long long x = std::atoll(v);
+  return x > 0 ? (size_t)x : dflt;
+}
+
+// Camera basis of Camera::get_ray (Camera.cpp:32-58, :91-92).
+DCamera device_camera(const mirt_camera &c, int width, int height) {
+  DCamera d;
+  std::memset(&d, 0, sizeof d);
+  const Vec3 gaze(c.gaze[0], c.gaze[1], c.gaze[2]), up(c.up[0], c.up[1], c.up[2]);
+  const Vec3 w = -gaze.norm();
+  const Vec3 u = up.cross(w).norm();
+  const Vec3 v = w.cross(u).norm();
+  const double aspect = static_cast<double>(width) / height;
+  const double scale_factor = 0.001;
+  for (int k = 0; k < 3; ++k) {
+    d.location[k] = c.location[k];
+    d.gaze[k] = c.gaze[k];
+    d.w[k] = w[k];
+    d.u[k] = u[k];
+    d.v[k] = v[k];
+  }
+  d.viewport_h = c.sensor_height * scale_factor;
+  d.viewport_w = d.viewport_h * aspect;
+  d.image_plane_dist = c.focal_length * scale_factor;
+  d.focus_distance = c.focus_distance;
+  d.dof = (c.dof_enabled && c.aperture_fstop > 0.0) ? 1 : 0;
+  d.aperture_radius = d.dof ? (c.focal_length * scale_factor) / (2.0 * c.aperture_fstop) : 0.0;
+  return d;
+}
+
+struct Timed {
+  hipEvent_t a, b;
+  int kind;  // 0 trace, 1 shadow
+};
+
+hipError_t get_event(mirt_scene *sc, size_t &used, hipEvent_t &e) {
+  if (used == sc->events.size()) {
+    hipEvent_t n;
+    hipError_t err = hipEventCreate(&n);
+    if (err != hipSuccess) return err;
+    sc->events.push_back(n);
+  }
+  e = sc->events[used++];
+  return hipSuccess;
+}
+
+}  // namespace
+
+MIRT_API int mirt_abi_version(void) { return MIRT_ABI_VERSION; }
+
+MIRT_API const char *mirt_last_error(void) { return g_error.c_str(); }
+
+MIRT_API int mirt_device_count(void) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(MIRT_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+MIRT_API void mirt_config_defaults(mirt_config *c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof *c);
+  c->max_ray_depth = 12;
+  c->shadow_samples = 16;
+  c->glossy_samples = 0;
+  c->enable_motion_blur = 1;
+  c->enable_textures = 1;
+  c->use_adaptive_epsilon = 1;
+  c->tone_mapping_mode = MIRT_TONEMAP_NONE;
+  c->enable_gamma_correction = 1;
+  c->light_intensity_factor = 0.2;
+  c->ambient_factor = 1.0;
+  c->ray_offset_epsilon = 0.001;
+  c->adaptive_epsilon_scale = 0.0001;
+  c->pure_glass_threshold = 0.99;
+  c->exposure = 1.0;
+  c->gamma = 2.2;
+  c->seed = 0;
+  c->sampling = MIRT_SAMPLING_JITTER;
+}
+
+MIRT_API void mirt_scene_destroy(mirt_scene *scene) {
+  if (!scene) return;
+  (void)hipSetDevice(scene->device);
+  delete scene;
+}
+
+MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
+  if (!out) return fail(MIRT_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (int rc = validate(desc)) return rc;
+  int n_dev = 0;
+  HIP_TRY(hipGetDeviceCount(&n_dev));
+  if (device < 0 || device >= n_dev) return fail(MIRT_ERR_DEVICE, "device %d not available (%d visible)", device, n_dev);
+  HIP_TRY(hipSetDevice(device));
+
+  mirt_scene *sc = new (std::nothrow) mirt_scene;
+  if (!sc) return fail(MIRT_ERR_MEMORY, "out of host memory");
+  struct Guard {
+    mirt_scene *s;
+    ~Guard() { delete s; }
+  } guard{sc};
+  sc->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->pinned), 64, hipHostMallocDefault));
+
+  const mirt_scene_desc &s = *desc;
+  std::vector<DNode> nodes(s.n_nodes);
+  if (fill_skip(s, nodes, 0) != s.n_nodes)
+    return fail(MIRT_ERR_INVALID, "BVH nodes are not one depth-first tree rooted at node 0");
+
+  std::vector<DPrim> prims(s.n_prims);
+  std::vector<DMotion> motion;
+  std::vector<double> transparency(s.n_prims);
+  bool any_maps = false;
+  for (int i = 0; i < s.n_prims; ++i) {
+    const mirt_prim &p = s.prims[i];
+    DPrim &d = prims[i];
+    std::memset(&d, 0, sizeof d);
+    d.type = p.type;
+    d.visible = p.visible;
+    d.material = p.material;
+    d.motion = MOTION_NONE;
+    std::memcpy(d.param, p.param, sizeof d.param);
+    transparency[i] = s.materials[p.material].transparency;
+    if (p.type == MIRT_PLANE) {  // no transform, no motion (Plane.cpp:8-92)
+      prepare_plane(s, p, d);
+      continue;
+    }
+    if (p.has_motion) {
+      // maps at shutter time 0.5 (all shadow rays, and all rays when motion blur is off), built
+      // the way the reference builds them per ray: interpolate, then invert (Sphere.cpp:9-11)
+      const Transform mid(Mat4::interpolate(mat_of(p.m0), mat_of(p.m1), 0.5));
+      store_3x4(d.xf, mid.world_to_object);
+      store_3x4(d.xf + 12, mid.object_to_world);
+      prepare_motion(p, d, motion);
+    } else {
+      store_3x4(d.xf, mat_of(p.w2o));
+      store_3x4(d.xf + 12, mat_of(p.o2w));
+    }
+  }
+  std::vector<mirt_material> materials(s.materials, s.materials + s.n_materials);
+  for (const auto &m : materials)
+    if ((m.has_texture && m.texture >= 0) || m.normal_map >= 0 || m.bump_map >= 0) any_maps = true;
+  sc->kinds = spawn_kinds(s);
+
+  std::vector<DTexture> textures(s.n_textures);
+  sc->texels.resize(s.n_textures);
+  for (int i = 0; i < s.n_textures; ++i) {
+    const mirt_texture &t = s.textures[i];
+    const size_t bytes = (size_t)t.width * t.height * 3 * sizeof(uint16_t);
+    HIP_TRY(sc->texels[i].reserve(bytes));
+    HIP_TRY(hipMemcpy(sc->texels[i].p, t.rgb, bytes, hipMemcpyHostToDevice));
+    textures[i].rgb = sc->texels[i].as<uint16_t>();
+    textures[i].width = t.width;
+    textures[i].height = t.height;
+    textures[i].max_value = t.max_value;
+    textures[i].inv_max = 1.0 / t.max_value;
+    textures[i].pad = 0;
+  }
+  sc->host_lights.assign(s.lights, s.lights + s.n_lights);
+  std::vector<int32_t> leaf(s.leaf_prims, s.leaf_prims + s.n_leaf_prims);
+
+  HIP_TRY(upload(sc->nodes, nodes));
+  HIP_TRY(upload(sc->leaf_prims, leaf));
+  HIP_TRY(upload(sc->prims, prims));
+  HIP_TRY(upload(sc->motion, motion));
+  HIP_TRY(upload(sc->materials, materials));
+  HIP_TRY(upload(sc->transparency, transparency));
+  HIP_TRY(upload(sc->lights, sc->host_lights));
+  HIP_TRY(upload(sc->textures, textures));
+  HIP_TRY(sc->light_frame.reserve(std::max<size_t>(sizeof(DLightFrame) * s.n_lights, 16)));
+  HIP_TRY(sc->counters.reserve(sizeof(DCounters) + 64));
+
+  DScene &d = sc->d;
+  d.nodes = sc->nodes.as<DNode>();
+  d.leaf_prims = sc->leaf_prims.as<int32_t>();
+  d.prims = sc->prims.as<DPrim>();
+  d.motion = sc->motion.as<DMotion>();
+  d.materials = sc->materials.as<mirt_material>();
+  d.prim_transparency = sc->transparency.as<double>();
+  d.lights = sc->lights.as<mirt_light>();
+  d.textures = sc->textures.as<DTexture>();
+  d.n_nodes = s.n_nodes;
+  d.n_prims = s.n_prims;
+  d.n_lights = s.n_lights;
+  d.n_textures = s.n_textures;
+  for (int k = 0; k < 3; ++k) d.background[k] = s.background_color[k] * s.background_strength;
+  d.any_motion = motion.empty() ? 0 : 1;
+  d.any_maps = any_maps ? 1 : 0;
+  d.max_children = 0;
+
+  guard.s = nullptr;
+  *out = sc;
+  return MIRT_OK;
+}
+
+MIRT_API int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int tile_h, int rank, int world) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;
+  const int64_t tiles = (int64_t)((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
+  const int64_t mine = tiles > rank ? (tiles - rank + world - 1) / world : 0;
+  return mine * tile_w * tile_h;
+}
+
+namespace {
+
+// One frame (or this rank's tiles of it) into a device buffer.
+int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *config, int width, int height,
+                  int spp, int tile_w, int tile_h, int rank, int world, double *d_out, hipStream_t stream,
+                  mirt_stats *stats) {
+  if (!sc || !camera || !config || !d_out) return fail(MIRT_ERR_INVALID, "NULL argument");
+  if (width <= 0 || height <= 0 || spp <= 0) return fail(MIRT_ERR_INVALID, "width, height and spp must be positive");
+  if (tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world)
+    return fail(MIRT_ERR_INVALID, "bad tile split: tile %dx%d rank %d of %d", tile_w, tile_h, rank, world);
+  if ((double)width * height * spp > 4.0e9) return fail(MIRT_ERR_UNSUPPORTED, "more than 4e9 samples in one frame");
+  HIP_TRY(hipSetDevice(sc->device));
+  if (!stream) stream = sc->stream;
+
+  DFrame fr;
+  std::memset(&fr, 0, sizeof fr);
+  fr.cam = device_camera(*camera, width, height);
+  fr.cfg = *config;
+  fr.width = width;
+  fr.height = height;
+  fr.spp = spp;
+  fr.tile_w = tile_w;
+  fr.tile_h = tile_h;
+  fr.tiles_x = (width + tile_w - 1) / tile_w;
+  fr.tiles_y = (height + tile_h - 1) / tile_h;
+  fr.rank = rank;
+  fr.world = world;
+  fr.blocks_x = (tile_w + 15) / 16;
+  fr.blocks_y = (tile_h + 15) / 16;
+  const int64_t tiles = (int64_t)fr.tiles_x * fr.tiles_y;
+  fr.n_slots = (int32_t)(tiles > rank ? (tiles - rank + world - 1) / world : 0);
+  const size_t n_pixels = (size_t)fr.n_slots * tile_w * tile_h;
+  const uint64_t total_blocks = (uint64_t)fr.n_slots * fr.blocks_x * fr.blocks_y;
+
+  // shadow strata per light for this frame (Raytracer.cpp:146-158)
+  const int n_lights = sc->d.n_lights;
+  std::vector<DLightFrame> lf(n_lights);
+  uint32_t dim = MIRT_DIM_SHADOW;
+  for (int l = 0; l < n_lights; ++l) {
+    const mirt_light &L = sc->host_lights[l];
+    int samples = (L.type == MIRT_LIGHT_AREA) ? std::max(1, L.samples) : 1;
+    if (config->shadow_samples > 0 && L.type == MIRT_LIGHT_AREA) samples = config->shadow_samples;
+    int side = static_cast<int>(std::sqrt(samples));
+    if (side * side == 0) side = 1;
+    lf[l].dim = dim;
+    lf[l].side = side;
+    lf[l].inv_n = 1.0 / (side * side);
+    dim += 2u * (uint32_t)(side * side);
+  }
+  if (n_lights) HIP_TRY(hipMemcpyAsync(sc->light_frame.p, lf.data(), sizeof(DLightFrame) * n_lights, hipMemcpyHostToDevice, stream));
+  fr.light_frame = sc->light_frame.as<DLightFrame>();
+
+  // working memory
+  const int K = max_children(sc->kinds, config->glossy_samples);
+  const int S = std::max(1, n_lights);
+  const size_t per_block = (size_t)256 * spp;
+  size_t want_rays = env_size("MIRT_RAY_QUEUE", (size_t)32 << 20);
+  size_t want_shadow = env_size("MIRT_SHADOW_QUEUE", (size_t)64 << 20);
+  // never more than the frame can produce, never less than one block's worth
+  want_rays = std::max(std::min(want_rays, (size_t)total_blocks * per_block * K), per_block * K);
+  want_shadow = std::max(std::min(want_shadow, (size_t)total_blocks * per_block * S), per_block * S);
+  if (want_rays > 0xfffffff0u || want_shadow > 0xfffffff0u) return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
+  if (want_rays > sc->ray_capacity) {
+    sc->ray_capacity = want_rays;
+    sc->queues.clear();
+  }
+  if (want_shadow > sc->shadow_capacity) sc->shadow_capacity = want_shadow;
+  HIP_TRY(sc->shadow_items.reserve(sc->shadow_capacity * sizeof(DShadowItem) + 64));
+  sc->shadow_count = reinterpret_cast<uint32_t *>(sc->shadow_items.as<char>() + sc->shadow_capacity * sizeof(DShadowItem));
+  HIP_TRY(sc->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
+  const size_t batch_rays = std::min(sc->ray_capacity / K, sc->shadow_capacity / S);  // rays one launch may trace
+
+  DCounters *counters = sc->counters.as<DCounters>();
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(DCounters), stream));
+  if (n_pixels) HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
+
+  const bool uv = sc->d.any_maps && config->enable_textures;
+  const bool motion = sc->d.any_motion && config->enable_motion_blur && config->sampling == MIRT_SAMPLING_JITTER;
+
+  size_t ev_used = 0;
+  std::vector<Timed> timed;
+  hipEvent_t ev_begin, ev_end;
+  HIP_TRY(get_event(sc, ev_used, ev_begin));
+  HIP_TRY(get_event(sc, ev_used, ev_end));
+  HIP_TRY(hipEventRecord(ev_begin, stream));
+  uint64_t launches = 0, secondary = 0, primary = 0;
+
+  // traces `n` rays of depth `depth` (from the camera when depth == 0, else from queue[depth]
+  // starting at `first`), then their shadow work, then -- recursively -- the rays they spawned
+  struct Runner {
+    mirt_scene *sc;
+    const DFrame &fr;
+    hipStream_t stream;
+    DCounters *counters;
+    bool uv, motion;
+    size_t batch_rays;
+    int K, S;
+    size_t &ev_used;
+    std::vector<Timed> &timed;
+    uint64_t &launches, &secondary;
+
+    int launch(int depth, uint32_t first, uint32_t n_units, uint32_t n_rays_or_blocks) {
+      (void)n_units;
+      const bool spawn = depth + 1 < fr.cfg.max_ray_depth;
+      if (spawn) HIP_TRY(ensure_queue(sc, depth + 1));
+      TraceArgs a;
+      std::memset(&a, 0, sizeof a);
+      a.sc = sc->d;
+      a.fr = fr;
+      if (depth > 0) a.in = sc->queues[depth].q;
+      if (spawn) {
+        a.out = sc->queues[depth + 1].q;
+        HIP_TRY(hipMemsetAsync(a.out.count, 0, sizeof(uint32_t), stream));
+      }
+      a.shadow = sc->shadow_items.as<DShadowItem>();
+      a.shadow_count = sc->shadow_count;
+      a.shadow_capacity = (uint32_t)sc->shadow_capacity;
+      a.accum = sc->accum.as<double>();
+      a.counters = counters;
+      a.first = first;
+      a.n = n_rays_or_blocks;
+      a.depth = depth;
+      HIP_TRY(hipMemsetAsync(sc->shadow_count, 0, sizeof(uint32_t), stream));
+      const unsigned grid = depth == 0 ? n_rays_or_blocks * (unsigned)fr.spp : (n_rays_or_blocks + 255u) / 256u;
+      Timed t{nullptr, nullptr, 0};
+      HIP_TRY(get_event(sc, ev_used, t.a));
+      HIP_TRY(get_event(sc, ev_used, t.b));
+      HIP_TRY(hipEventRecord(t.a, stream));
+      launch_trace(depth == 0, uv, depth == 0 ? motion : motion, grid, stream, a);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(t.b, stream));
+      timed.push_back(t);
+      launches++;
+      // counts of what it produced
+      sc->pinned[0] = 0;
+      if (spawn) HIP_TRY(hipMemcpyAsync(&sc->pinned[0], a.out.count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(&sc->pinned[1], sc->shadow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      const uint32_t n_children = sc->pinned[0], n_shadow = sc->pinned[1];
+      if (n_children > sc->ray_capacity || n_shadow > sc->shadow_capacity)
+        return fail(MIRT_ERR_DEVICE, "internal: queue overflow (%u rays, %u shadow items)", n_children, n_shadow);
+      if (n_shadow) {
+        ShadowArgs s;
+        std::memset(&s, 0, sizeof s);
+        s.sc = sc->d;
+        s.fr = fr;
+        s.items = sc->shadow_items.as<DShadowItem>();
+        s.n = n_shadow;
+        s.accum = sc->accum.as<double>();
+        s.counters = counters;
+        Timed ts{nullptr, nullptr, 1};
+        HIP_TRY(get_event(sc, ev_used, ts.a));
+        HIP_TRY(get_event(sc, ev_used, ts.b));
+        HIP_TRY(hipEventRecord(ts.a, stream));
+        launch_shadow((n_shadow + 255u) / 256u, stream, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ts.b, stream));
+        timed.push_back(ts);
+        launches++;
+      }
+      if (n_children) return run_queue(depth + 1, n_children);
+      return MIRT_OK;
+    }
+
+    int run_queue(int depth, uint32_t n) {
+      secondary += n;
+      const uint32_t chunk = (uint32_t)std::min<size_t>(n, batch_rays);
+      for (uint32_t first = 0; first < n; first += chunk) {
+        const uint32_t m = std::min(chunk, n - first);
+        if (int rc = launch(depth, first, m, m)) return rc;
+      }
+      return MIRT_OK;
+    }
+  };
+  Runner run{sc, fr, stream, counters, uv, motion, batch_rays, K, S, ev_used, timed, launches, secondary};
+
+  if (config->max_ray_depth > 0 && total_blocks > 0) {
+    const uint64_t blocks_per_launch = std::max<uint64_t>(1, batch_rays / per_block);
+    for (uint64_t b0 = 0; b0 < total_blocks; b0 += blocks_per_launch) {
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(blocks_per_launch, total_blocks - b0);
+      if (int rc = run.launch(0, (uint32_t)b0, nb, nb)) return rc;
+    }
+    primary = (uint64_t)width * height * spp;
+    if (world > 1 || tile_w != width || tile_h != height) {
+      // samples of the pixels this rank owns
+      uint64_t px = 0;
+      for (int64_t t = rank; t < tiles; t += world) {
+        const int tx = (int)(t % fr.tiles_x), ty = (int)(t / fr.tiles_x);
+        px += (uint64_t)std::min(tile_w, width - tx * tile_w) * std::min(tile_h, height - ty * tile_h);
+      }
+      primary = px * spp;
+    }
+  }
+
+  if (n_pixels) {
+    ResolveArgs r;
+    std::memset(&r, 0, sizeof r);
+    r.accum = sc->accum.as<double>();
+    r.out = d_out;
+    r.n_pixels = (uint32_t)n_pixels;
+    r.spp = spp;
+    r.cfg = *config;
+    launch_resolve((unsigned)((n_pixels + 255) / 256), stream, r);
+    HIP_TRY(hipGetLastError());
+    launches++;
+  }
+  HIP_TRY(hipEventRecord(ev_end, stream));
+  HIP_TRY(hipMemcpyAsync(sc->pinned + 4, counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    DCounters c;
+    std::memcpy(&c, sc->pinned + 4, sizeof c);
+    stats->primary_rays = primary;
+    stats->secondary_rays = secondary;
+    stats->shadow_segments = c.shadow_segments;
+    stats->node_tests = c.node_tests;
+    stats->prim_tests = c.prim_tests;
+    stats->launches = launches;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    stats->device_ms = ms;
+    for (const Timed &t : timed) {
+      HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+      if (t.kind == 0) {
+        stats->trace_kernel_ms += ms;
+        stats->trace_kernel_launches++;
+      } else {
+        stats->shadow_kernel_ms += ms;
+        stats->shadow_kernel_launches++;
+      }
+    }
+  }
+  return MIRT_OK;
+}
+
+}  // namespace
+
+MIRT_API int mirt_render_tiles(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
+                               int height, int spp, int tile_w, int tile_h, int rank, int world, double *d_rgb_out,
+                               void *stream, mirt_stats *stats) {
+  return render_device(scene, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
+                       static_cast<hipStream_t>(stream), stats);
+}
+
+MIRT_API int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
+                         int height, int spp, double *rgb_out, mirt_stats *stats) {
+  if (!scene || !rgb_out) return fail(MIRT_ERR_INVALID, "NULL argument");
+  if (width <= 0 || height <= 0) return fail(MIRT_ERR_INVALID, "width and height must be positive");
+  HIP_TRY(hipSetDevice(scene->device));
+  const size_t bytes = (size_t)width * height * 3 * sizeof(double);
+  HIP_TRY(scene->out.reserve(bytes));
+  if (int rc = render_device(scene, camera, config, width, height, spp, width, height, 0, 1, scene->out.as<double>(),
+                             nullptr, stats))
+    return rc;
+  HIP_TRY(hipMemcpy(rgb_out, scene->out.p, bytes, hipMemcpyDeviceToHost));
+  return MIRT_OK;
+}
+
+MIRT_API int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int width, int height, int32_t *prim_id,
+                            double *t, double *normal, double *uv) {
+  if (!scene || !camera || !prim_id) return fail(MIRT_ERR_INVALID, "NULL argument");
+  if (width <= 0 || height <= 0) return fail(MIRT_ERR_INVALID, "width and height must be positive");
+  HIP_TRY(hipSetDevice(scene->device));
+  const size_t n = (size_t)width * height;
+  // layout: ids | t | normal | uv
+  const size_t off_t = (n * sizeof(int32_t) + 63) & ~(size_t)63;
+  const size_t off_n = off_t + n * sizeof(double);
+  const size_t off_uv = off_n + 3 * n * sizeof(double);
+  HIP_TRY(scene->ids.reserve(off_uv + 2 * n * sizeof(double)));
+  char *base = scene->ids.as<char>();
+  mirt_camera pin = *camera;
+  pin.dof_enabled = 0;
+  IdsArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.sc = scene->d;
+  a.cam = device_camera(pin, width, height);
+  a.width = width;
+  a.height = height;
+  a.prim_id = reinterpret_cast<int32_t *>(base);
+  a.t = reinterpret_cast<double *>(base + off_t);
+  a.normal = reinterpret_cast<double *>(base + off_n);
+  a.uv = reinterpret_cast<double *>(base + off_uv);
+  const unsigned grid = (unsigned)(((width + 15) / 16) * ((height + 15) / 16));
+  launch_trace_ids(grid, scene->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(scene->stream));
+  HIP_TRY(hipMemcpy(prim_id, a.prim_id, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (t) HIP_TRY(hipMemcpy(t, a.t, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (normal) HIP_TRY(hipMemcpy(normal, a.normal, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (uv) HIP_TRY(hipMemcpy(uv, a.uv, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+  return MIRT_OK;
+}

@@ -1,0 +1,623 @@
+// The render pipeline kernels (gfx950, 64-lane waves):
+//
+//   k_trace<PRIMARY>   one lane per ray: generate it (PRIMARY) or read it from the depth's ray queue,
+//                      find the closest hit by the wave-coherent BVH walk below, shade it without
+//                      visibility (ambient, emission, per-light Blinn-Phong terms), append one shadow
+//                      work item per contributing light and the reflection / glossy / refraction rays
+//                      to the next depth's queue (wave ballot + one atomic per wave and queue).
+//   k_shadow           one lane per (hit, light): walks the strata of the light, each as a chain of
+//                      closest-hit segments through transparent objects, then adds the light's
+//                      contribution times its visibility to the pixel.
+//   k_resolve          mean over samples, tone map, gamma.
+//   k_trace_ids        parity hook: closest hit of pixel-centre rays.
+//
+// The ray tree of the reference's recursive trace() (Code/Render/Raytracer.cpp:296-473) is linear in
+// the colours its children return, so every ray carries the RGB weight with which its radiance
+// enters the pixel and the tree is processed one depth at a time.
+//
+// BVH walk: nodes are stored in the reference's own visiting order with skip links, so the walk
+// needs no stack, and it is driven per WAVE: the node index is wave-uniform, node and primitive
+// records are fetched once per wave through the scalar data path, and every lane tests its own ray
+// against them (lanes whose ray missed a box sleep until the walk leaves that subtree).  Primitive
+// kind and transform kind are therefore uniform branches: the six intersectors never diverge
+// against each other inside a wave.
+#pragma once
+
+#include "geometry.h"
+#include "mirt_rng.h"
+
+#define WAVE 64
+
+DEV double maxd(double a, double b) { return (a < b) ? b : a; }  // std::max(a, b)
+DEV double mind(double a, double b) { return (b < a) ? b : a; }  // std::min(a, b)
+
+// BoundingBox::intersect (BoundingBox.h:14-31), NaN behaviour of std::max / std::min included.
+DEV bool box_hit(const DNode &n, const RayL &r, double t_min, double t_max) {
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const double inv = comp(r.inv, a), o = comp(r.o, a);
+    double t0 = (n.bmin[a] - o) * inv;
+    double t1 = (n.bmax[a] - o) * inv;
+    if (inv < 0.0) {
+      const double s = t0;
+      t0 = t1;
+      t1 = s;
+    }
+    t_min = maxd(t0, t_min);
+    t_max = mind(t1, t_max);
+    if (t_max <= t_min) return false;
+  }
+  return true;
+}
+
+// intersect_bvh (Bvh.cpp:306-333) for the 64 rays of a wave at once.  Must be called by all lanes
+// of the wave; `active` masks the lanes that have a ray.
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
+                         Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
+  const int n_nodes = sc.n_nodes;
+  int resume = active ? 0 : 0x7fffffff;  // first node at which this lane takes part again
+  int node = 0;
+  while (node < n_nodes) {
+    const int un = __builtin_amdgcn_readfirstlane(node);
+    const DNode &nd = sc.nodes[un];
+    const bool on = resume <= un;
+    bool hit = false;
+    if (on) {
+      n_node++;
+      hit = box_hit(nd, ray, t_min, closest_t);
+      if (!hit) resume = nd.skip;
+    }
+    if (!__any(hit)) {
+      node = nd.skip;
+      continue;
+    }
+    if (nd.first >= 0) {
+      for (int k = 0; k < nd.count; k++) {
+        const int pi = __builtin_amdgcn_readfirstlane(sc.leaf_prims[nd.first + k]);
+        const DPrim &pr = sc.prims[pi];
+        if (hit) {
+          n_prim++;
+          isect_prim<SHADOW, UV, MOTION>(sc, pr, pi, ray, t_min, closest_t, best);
+        }
+      }
+      node = nd.skip;
+    } else {
+      node = un + 1;
+    }
+  }
+}
+
+// What shading needs from a hit (HitRecord, HitRecord.h:8-32).
+template <bool UV> struct Surface;
+template <> struct Surface<false> {
+  d3 p, n;
+  bool front;
+};
+template <> struct Surface<true> {
+  d3 p, n;
+  bool front;
+  double u, v;
+  d3 tan, bit;
+};
+
+DEV void finish_frame(Surface<false> &, const Best<false> &, bool) {}
+DEV void finish_frame(Surface<true> &s, const Best<true> &b, bool plane) {
+  s.u = b.u;
+  s.v = b.v;
+  if (plane) {
+    s.tan = b.tan;  // Plane.cpp:124
+  } else {
+    d3 t = unit(unit(b.tan));  // Transform.cpp:112-114 then e.g. Sphere.cpp:72
+    s.tan = unit(t - s.n * dot(t, s.n));
+  }
+  s.bit = unit(cross(s.n, s.tan));
+}
+
+// Normalisation and face-forwarding of the winning hit (Transform.cpp:107-109, HitRecord.h:28-31).
+template <bool UV> DEV Surface<UV> make_surface(const DScene &sc, const RayL &ray, const Best<UV> &b) {
+  Surface<UV> s;
+  const bool plane = sc.prims[b.prim].type == MIRT_PLANE;
+  const d3 n = plane ? b.n : unit(unit(b.n));
+  s.front = dot(ray.d, n) < 0;
+  s.n = s.front ? n : -n;
+  s.p = b.p;
+  finish_frame(s, b, plane);
+  return s;
+}
+
+// TextureManager::sample (Texture.cpp:74-150): clamp, flip v, bilinear with wrapped neighbours.
+DEV d3 tex_sample(const DTexture &tx, double u, double v) {
+  const int w = tx.width, h = tx.height;
+  u = maxd(0.0, mind(1.0, u));
+  v = maxd(0.0, mind(1.0, v));
+  v = 1.0 - v;
+  const double x = u * w - 0.5, y = v * h - 0.5;
+  const int xf = (int)floor(x), yf = (int)floor(y);
+  const double ur = x - xf, vr = y - yf;
+  const int x0 = (xf % w + w) % w, x1 = (x0 + 1) % w;
+  const int y0 = (yf % h + h) % h, y1 = (y0 + 1) % h;
+  const double mv = (double)tx.max_value;
+  auto px = [&](int yy, int xx) {
+    const uint16_t *q = tx.rgb + 3 * ((size_t)yy * w + xx);
+    return mk((double)q[0] / mv, (double)q[1] / mv, (double)q[2] / mv);
+  };
+  const d3 c00 = px(y0, x0), c10 = px(y0, x1), c01 = px(y1, x0), c11 = px(y1, x1);
+  const d3 top = c00 + (c10 - c00) * ur;
+  const d3 bot = c01 + (c11 - c01) * ur;
+  return top + (bot - top) * vr;
+}
+
+// apply_normal_map (Raytracer.cpp:220-242)
+DEV d3 shading_normal(const DScene &, const mirt_config &, const mirt_material &, const Surface<false> &s) {
+  return s.n;
+}
+DEV d3 shading_normal(const DScene &sc, const mirt_config &cfg, const mirt_material &m, const Surface<true> &s) {
+  if (cfg.enable_textures && m.normal_map >= 0) {
+    const d3 ns = tex_sample(sc.textures[m.normal_map], s.u, s.v);
+    d3 tn = mk(ns.x * 2.0 - 1.0, ns.y * 2.0 - 1.0, ns.z * 2.0 - 1.0);
+    tn.x *= m.bump_strength;
+    tn.y *= m.bump_strength;
+    tn = unit(tn);
+    return unit(s.tan * tn.x + s.bit * tn.y + s.n * tn.z);
+  }
+  if (cfg.enable_textures && m.bump_map >= 0) {
+    const DTexture &tx = sc.textures[m.bump_map];
+    const double delta = 0.001;
+    auto height = [&](double u, double v) {
+      const d3 c = tex_sample(tx, u, v);
+      return 0.299 * c.x + 0.587 * c.y + 0.114 * c.z;
+    };
+    const double hc = height(s.u, s.v);
+    const double dU = (height(s.u + delta, s.v) - hc) / delta;
+    const double dV = (height(s.u, s.v + delta) - hc) / delta;
+    const double scale = 10.0 * m.bump_strength;
+    return unit(s.n - s.tan * dU * scale - s.bit * dV * scale);
+  }
+  return s.n;
+}
+DEV bool base_texture(const DScene &, const mirt_config &, const mirt_material &, const Surface<false> &, d3 &) {
+  return false;
+}
+DEV bool base_texture(const DScene &sc, const mirt_config &cfg, const mirt_material &m, const Surface<true> &s,
+                      d3 &tex) {
+  if (cfg.enable_textures && m.has_texture && m.texture >= 0) {  // Raytracer.cpp:250-251, :391-392
+    tex = tex_sample(sc.textures[m.texture], s.u, s.v);
+    return true;
+  }
+  return false;
+}
+
+// Camera::get_ray (Camera.cpp:10-111); the camera basis comes pre-computed in DCamera.
+DEV void camera_ray(const DCamera &c, double x, double y, int width, int height, uint64_t key, d3 &origin, d3 &dir) {
+  const double ndc_x = x / width, ndc_y = y / height;
+  const double vx = (ndc_x - 0.5) * c.viewport_w, vy = (0.5 - ndc_y) * c.viewport_h;
+  const d3 loc = ld3(c.location), w = ld3(c.w), u = ld3(c.u), v = ld3(c.v);
+  const d3 image_point = loc - w * c.image_plane_dist + u * vx + v * vy;
+  origin = loc;
+  dir = unit(image_point - loc);
+  if (c.dof) {
+    const double t = c.focus_distance / dot(ld3(c.gaze), dir);
+    const d3 focus = origin + dir * t;
+    const double r1 = mirt_rng_draw(key, MIRT_DIM_LENS_R1), r2 = mirt_rng_draw(key, MIRT_DIM_LENS_R2);
+    const double r = c.aperture_radius * sqrt(r1);
+    double sn, cs;
+    sincos(2.0 * M_PI * r2, &sn, &cs);
+    const d3 lens = loc + u * (r * cs) + v * (r * sn);
+    origin = lens;
+    dir = unit(focus - lens);
+  }
+}
+
+// Light::sample_point (Light.h:38-69)
+DEV d3 light_point(const mirt_light &l, double u, double v) {
+  if (l.type != MIRT_LIGHT_AREA) return ld3(l.location);
+  d3 n = ld3(l.normal);
+  if (len2(n) < 0.1) n = mk(0, 0, -1);
+  n = unit(n);
+  d3 right = fabs(n.x) > 0.9 ? mk(0, 1, 0) : mk(1, 0, 0);
+  right = unit(cross(n, right));
+  const d3 up = unit(cross(n, right));
+  if (l.area_shape == MIRT_AREA_RECT)
+    return ld3(l.location) + right * ((u - 0.5) * l.area_size[0]) + up * ((v - 0.5) * l.area_size[1]);
+  const double r = sqrt(u);
+  double sn, cs;
+  sincos(2.0 * 3.14159265359 * v, &sn, &cs);
+  return ld3(l.location) + right * (r * cs * (l.area_size[0] * 0.5)) + up * (r * sn * (l.area_size[1] * 0.5));
+}
+
+DEV void pixel_add(double *accum, uint32_t pixel, d3 c) {
+  double *p = accum + 3 * (size_t)pixel;
+  unsafeAtomicAdd(p, c.x);
+  unsafeAtomicAdd(p + 1, c.y);
+  unsafeAtomicAdd(p + 2, c.z);
+}
+
+// Appends one ray per pushing lane: the wave counts its pushers with a ballot, one lane reserves
+// the range with a single atomic, every pusher writes at base + its rank among the pushers.
+DEV void queue_push(const DRayQueue &q, bool push, d3 o, d3 d, double time, d3 w, uint64_t key, uint32_t pixel) {
+  const unsigned long long mask = __ballot(push);
+  if (mask == 0) return;
+  const int lane = __lane_id();
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(q.count, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (push) {
+    const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (i < q.capacity) {  // the host sizes every launch so that this always holds
+      q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
+      q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
+      q.time[i] = time;
+      q.wr[i] = w.x; q.wg[i] = w.y; q.wb[i] = w.z;
+      q.key[i] = key;
+      q.pixel[i] = pixel;
+    }
+  }
+}
+
+DEV void shadow_push(DShadowItem *items, uint32_t *count, uint32_t capacity, bool push, d3 p, d3 c, uint64_t key,
+                     uint32_t pixel, uint32_t light) {
+  const unsigned long long mask = __ballot(push);
+  if (mask == 0) return;
+  const int lane = __lane_id();
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (push) {
+    const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (i < capacity) {
+      DShadowItem it;
+      it.p[0] = p.x; it.p[1] = p.y; it.p[2] = p.z;
+      it.c[0] = c.x; it.c[1] = c.y; it.c[2] = c.z;
+      it.key = key;
+      it.pixel = pixel;
+      it.light = light;
+      items[i] = it;
+    }
+  }
+}
+
+DEV void count_add(unsigned long long *dst, unsigned v) {
+  // wave sum, then one atomic per wave
+  unsigned s = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (__lane_id() == 0 && s) atomicAdd(dst, (unsigned long long)s);
+}
+
+DEV d3 reflect_dir(d3 i, d3 n) { return i - n * 2.0 * dot(i, n); }  // Raytracer.cpp:210-212
+
+
+// Pixel of lane `p` (0..255) of 16x16 block `block` of this rank's tiles: four 8x8 waves per block.
+DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int &gy, uint32_t &slot_pixel) {
+  const uint32_t per_tile = (uint32_t)(fr.blocks_x * fr.blocks_y);
+  const uint32_t slot = block / per_tile, b = block % per_tile;
+  const int tile = fr.rank + (int)slot * fr.world;
+  const int tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
+  const uint32_t wv = p >> 6, ln = p & 63;
+  const int lx = (int)((b % fr.blocks_x) * 16 + (wv & 1) * 8 + (ln & 7));
+  const int ly = (int)((b / fr.blocks_x) * 16 + (wv >> 1) * 8 + (ln >> 3));
+  gx = tx * fr.tile_w + lx;
+  gy = ty * fr.tile_h + ly;
+  slot_pixel = slot * (uint32_t)(fr.tile_w * fr.tile_h) + (uint32_t)(ly * fr.tile_w + lx);
+  return lx < fr.tile_w && ly < fr.tile_h && gx < fr.width && gy < fr.height;
+}
+
+template <bool PRIMARY, bool UV, bool MOTION>
+__global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
+  const DScene &sc = a.sc;
+  const mirt_config &cfg = a.fr.cfg;
+  bool active;
+  d3 ro, rd, W;
+  double time;
+  uint64_t key;
+  uint32_t pixel;
+  if (PRIMARY) {
+    // grid: (block, sample) pairs; 256 threads = one 16x16 pixel block at one sample index
+    const uint32_t bs = blockIdx.x;
+    const uint32_t block = a.first + bs / (uint32_t)a.fr.spp;
+    const uint32_t s = bs % (uint32_t)a.fr.spp;
+    int gx, gy;
+    active = block_pixel(a.fr, block, threadIdx.x, gx, gy, pixel);
+    key = mirt_rng_sample_key(cfg.seed, (uint32_t)(gy * a.fr.width + gx), s);
+    double u, v;
+    if (cfg.sampling == MIRT_SAMPLING_CENTRE) {  // deterministic parity mode
+      u = gx + 0.5;
+      v = gy + 0.5;
+      time = 0.5;
+    } else {  // Raytracer.cpp:533-538
+      u = gx + mirt_rng_draw(key, MIRT_DIM_JITTER_U);
+      v = gy + mirt_rng_draw(key, MIRT_DIM_JITTER_V);
+      time = cfg.enable_motion_blur ? mirt_rng_draw(key, MIRT_DIM_TIME) : 0.5;
+    }
+    camera_ray(a.fr.cam, u, v, a.fr.width, a.fr.height, key, ro, rd);
+    W = mk(1, 1, 1);
+  } else {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    active = i < a.n;
+    const uint32_t j = a.first + (active ? i : 0);
+    ro = mk(a.in.ox[j], a.in.oy[j], a.in.oz[j]);
+    rd = mk(a.in.dx[j], a.in.dy[j], a.in.dz[j]);
+    time = a.in.time[j];
+    W = mk(a.in.wr[j], a.in.wg[j], a.in.wb[j]);
+    key = a.in.key[j];
+    pixel = a.in.pixel[j];
+  }
+
+  const RayL ray = make_ray(ro, rd, time);
+  Best<UV> best;
+  best.prim = -1;
+  best.t = 0;
+  best.p = mk(0, 0, 0);
+  best.n = mk(0, 0, 1);
+  double closest = 1.7976931348623157e308;  // numeric_limits<double>::max() (Raytracer.cpp:300)
+  unsigned n_node = 0, n_prim = 0;
+  traverse_packet<false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
+  count_add(&a.counters->node_tests, n_node);
+  count_add(&a.counters->prim_tests, n_prim);
+
+  const bool hit = active && best.prim >= 0;
+  if (active && !hit) pixel_add(a.accum, pixel, W * ld3(sc.background));  // Raytracer.cpp:472
+
+  // ---- shading of the hit (Raytracer.cpp:305-466), visibility deferred to k_shadow ------------
+  const bool spawn = a.depth + 1 < cfg.max_ray_depth;  // deeper rays would return black (Raytracer.cpp:297)
+  const int pidx = hit ? best.prim : 0;
+  const mirt_material &m = sc.materials[sc.prims[pidx].material];
+  Surface<UV> sf = {};
+  d3 sn = mk(0, 0, 1), tint = mk(0, 0, 0), amb = mk(0, 0, 0);
+  double R = 0, T = 0, eps = 0;
+  bool pass = false, glass = false, tir = false;
+  double fres = 0;
+  d3 perp = mk(0, 0, 0);
+  double disc = 0;
+  d3 wd = mk(0, 0, 0), ws = mk(0, 0, 0);
+  bool lit = false;
+  if (hit) {
+    sf = make_surface<UV>(sc, ray, best);
+    sn = shading_normal(sc, cfg, m, sf);
+    R = m.reflectivity;
+    T = m.transparency;
+    tint = ld3(m.diffuse);
+    amb = ld3(m.ambient);
+    d3 tex;
+    if (base_texture(sc, cfg, m, sf, tex)) {
+      tint = tex * ld3(m.diffuse);
+      amb = tex * ld3(m.ambient);
+    }
+    eps = cfg.ray_offset_epsilon;
+    if (cfg.use_adaptive_epsilon) eps += len(sf.p) * cfg.adaptive_epsilon_scale;
+    glass = T > 0.0;
+    if (glass) {  // Raytracer.cpp:414-464
+      const double eta = sf.front ? (1.0 / m.refractive_index) : m.refractive_index;
+      const double ct = fabs(dot(ray.d, sf.n));
+      double r0 = (eta - 1.0) / (eta + 1.0);
+      r0 = r0 * r0;
+      fres = r0 + (1.0 - r0) * pow(1.0 - ct, 5.0);
+      perp = (ray.d + sf.n * ct) * eta;
+      disc = 1.0 - len2(perp);
+      tir = !(disc >= 0);
+      pass = !tir && T >= 0.99;  // `return combined`: every local term is dropped (Raytracer.cpp:456-458)
+    }
+    if (!pass) {
+      const double kT = glass ? (1.0 - T) : 1.0;
+      ws = W * kT;
+      wd = (R > 0.0) ? ws * (1.0 - R) : ws;  // Raytracer.cpp:408-410
+      d3 local = ld3(m.emission) * m.emission_strength;
+      local = W * local;
+      lit = !(T >= cfg.pure_glass_threshold);  // pure glass is not shaded (Raytracer.cpp:307-311)
+      if (lit) local = local + wd * (amb * cfg.ambient_factor);
+      pixel_add(a.accum, pixel, local);
+    }
+  }
+
+  // per-light unshadowed Blinn-Phong terms -> shadow work items (Raytracer.cpp:262-286)
+  for (int li = 0; li < sc.n_lights; li++) {
+    const mirt_light &L = sc.lights[li];
+    bool push = false;
+    d3 c = mk(0, 0, 0);
+    if (hit && lit) {
+      const d3 to = ld3(L.location) - sf.p;
+      const double dist = len(to);
+      const d3 ldir = to / dist;
+      const d3 lin = ld3(L.color) * (L.intensity * cfg.light_intensity_factor / (dist * dist));
+      const double ndl = maxd(0.0, dot(sn, ldir));
+      if (ndl > 0.0) {
+        c = wd * (tint * ndl) * lin;
+        const d3 half = unit(ldir + (-ray.d));
+        const double ndh = maxd(0.0, dot(sn, half));
+        if (ndh > 0.0) c = c + ws * (ld3(m.specular) * pow(ndh, m.shininess)) * lin;
+        push = true;
+      }
+    }
+    shadow_push(a.shadow, a.shadow_count, a.shadow_capacity, push, sf.p, c, key, pixel, (uint32_t)li);
+  }
+
+  if (!spawn) return;  // wave-uniform
+
+  // ---- reflection (Raytracer.cpp:317-411); dropped when the glass branch returns `combined` ----
+  {
+    const bool refl = hit && R > 0.0 && !pass;
+    const d3 r = reflect_dir(ray.d, sn);
+    int samples = 1;
+    if (cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
+    const bool mirror = samples == 1 || m.glossiness > 0.94;
+    const bool metal = R > 0.5 && T < 0.1;
+    d3 cw = ws * R;
+    if (metal) cw = cw * tint;
+    const d3 org = sf.p + sf.n * eps;
+    queue_push(a.out, refl && mirror, org, r, time, cw, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY), pixel);
+    const bool lobe = refl && !mirror;
+    if (__any(lobe)) {
+      const d3 w = r;
+      const d3 u = unit(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
+      const d3 v = cross(w, u);
+      const double expo = pow(10.0, m.glossiness * 4.0);
+      const d3 cws = cw / (double)samples;
+      for (int i = 0; i < cfg.glossy_samples; i++) {
+        const bool on = lobe && i < samples;
+        const double r1 = mirt_rng_draw(key, MIRT_DIM_GLOSSY + 2u * i);
+        const double r2 = mirt_rng_draw(key, MIRT_DIM_GLOSSY + 2u * i + 1);
+        const double ct = pow(r1, 1.0 / (expo + 1.0));
+        const double st = sqrt(maxd(0.0, 1.0 - ct * ct));
+        double sp, cp;
+        sincos(2.0 * M_PI * r2, &sp, &cp);
+        d3 dir = unit(u * (st * cp) + v * (st * sp) + w * ct);
+        if (dot(dir, sf.n) < 0) dir = r;
+        queue_push(a.out, on, org, dir, time, cws, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY + i), pixel);
+      }
+    }
+  }
+  // ---- Fresnel reflection and refraction (Raytracer.cpp:414-464) --------------------------------
+  {
+    const bool g = hit && glass;
+    const d3 wbase = pass ? W : W * T;
+    const d3 wr = tir ? wbase : wbase * fres;
+    queue_push(a.out, g, sf.p + sf.n * eps, reflect_dir(ray.d, sf.n), time, wr,
+               mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFLECT), pixel);
+    const d3 para = sf.n * (-sqrt(maxd(0.0, disc)));
+    queue_push(a.out, g && !tir, sf.p - sf.n * eps, perp + para, time, wbase * (1.0 - fres),
+               mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFRACT), pixel);
+  }
+}
+
+
+// Raytracer::compute_shadow (Raytracer.cpp:145-208) for one (hit, light) pair per lane.  Each lane
+// is a small state machine -- stratum index, distance walked, attenuation -- and the wave runs
+// closest-hit segments until every lane is done, so lanes with many strata or glass on the way do
+// not hold the others idle between their segments.  Shadow rays are at shutter time 0.5 (Ray.h:15).
+__global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
+  const DScene &sc = a.sc;
+  const mirt_config &cfg = a.fr.cfg;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool valid = i < a.n;
+  const DShadowItem it = a.items[valid ? i : 0];
+  const d3 P = ld3(it.p);
+  const mirt_light &L = sc.lights[it.light];
+  const DLightFrame lf = a.fr.light_frame[it.light];
+  const int side = lf.side, n = side * side;
+  double eps = cfg.ray_offset_epsilon;
+  if (cfg.use_adaptive_epsilon) eps += len(P) * cfg.adaptive_epsilon_scale;
+
+  int s = 0;
+  double total = 0.0, att = 1.0, cur = 0.0, dist = 0.0;
+  d3 dir = mk(0, 0, 1);
+  bool busy = false;
+  // moves to the next stratum that has a segment to walk; returns false when all strata are done
+  auto next_stratum = [&]() {
+    while (s < n) {
+      const int si = s / side, sj = s % side;
+      const uint32_t dim = lf.dim + 2u * (uint32_t)s;
+      const double u = (si + mirt_rng_draw(it.key, dim)) / side;
+      const double v = (sj + mirt_rng_draw(it.key, dim + 1)) / side;
+      const d3 to = light_point(L, u, v) - P;
+      dist = len(to);
+      dir = to / dist;
+      att = 1.0;
+      cur = eps;
+      if (cur < dist) return true;
+      s++;  // nothing to walk: this stratum is unoccluded
+    }
+    return false;
+  };
+  if (valid) busy = next_stratum();
+
+  unsigned n_node = 0, n_prim = 0, n_seg = 0;
+  while (__any(busy)) {
+    const RayL ray = make_ray(P + dir * cur, dir, 0.5);
+    double closest = dist - cur;
+    Best<false> best;
+    best.prim = -1;
+    best.t = 0;
+    if (busy) n_seg++;
+    traverse_packet<true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+    if (busy) {
+      bool done = true;
+      if (best.prim >= 0 && best.t < (dist - cur)) {
+        const double tr = sc.prim_transparency[best.prim];
+        if (tr > 0.0) {
+          const double opacity = 1.0 - tr;
+          att *= (1.0 - opacity);
+          cur += best.t + eps;
+          done = (att < 0.01) || !(cur < dist);
+        } else {
+          att = 0.0;
+        }
+      }
+      if (done) {
+        total += (1.0 - att);
+        s++;
+        busy = next_stratum();
+      }
+    }
+  }
+  count_add(&a.counters->node_tests, n_node);
+  count_add(&a.counters->prim_tests, n_prim);
+  count_add(&a.counters->shadow_segments, n_seg);
+  if (valid) {
+    const double shadow = total * lf.inv_n;
+    if (!(shadow >= 1.0)) pixel_add(a.accum, it.pixel, ld3(it.c) * (1.0 - shadow));  // Raytracer.cpp:264,271
+  }
+}
+
+
+// Raytracer.cpp:544-568: mean, optional tone map, gamma on un-clamped values.
+__global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= a.n_pixels) return;
+  double c[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double x = a.accum[3 * (size_t)i + k] / a.spp;
+    if (a.cfg.tone_mapping_mode == MIRT_TONEMAP_REINHARD) {
+      x = x / (1.0 + x);
+    } else if (a.cfg.tone_mapping_mode == MIRT_TONEMAP_EXPOSURE) {
+      x *= a.cfg.exposure;
+      x = mind(1.0, x);
+    }
+    if (a.cfg.enable_gamma_correction) x = pow(x, 1.0 / a.cfg.gamma);
+    c[k] = x;
+  }
+  a.out[3 * (size_t)i] = c[0];
+  a.out[3 * (size_t)i + 1] = c[1];
+  a.out[3 * (size_t)i + 2] = c[2];
+}
+
+
+// Closest hit of the pixel-centre camera rays at time 0.5 (pinhole): the parity hook.
+__global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
+  const uint32_t bx = blockIdx.x % ((a.width + 15) / 16), by = blockIdx.x / ((a.width + 15) / 16);
+  const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int gx = (int)(bx * 16 + (wv & 1) * 8 + (ln & 7)), gy = (int)(by * 16 + (wv >> 1) * 8 + (ln >> 3));
+  const bool active = gx < a.width && gy < a.height;
+  d3 ro, rd;
+  camera_ray(a.cam, gx + 0.5, gy + 0.5, a.width, a.height, 0, ro, rd);
+  const RayL ray = make_ray(ro, rd, 0.5);
+  Best<true> best;
+  best.prim = -1;
+  best.t = 0;
+  best.p = mk(0, 0, 0);
+  best.n = mk(0, 0, 1);
+  best.u = best.v = 0;
+  best.tan = mk(1, 0, 0);
+  double closest = 1.7976931348623157e308;
+  unsigned nn = 0, np = 0;
+  traverse_packet<false, true, false>(a.sc, ray, active, 1e-5, closest, best, nn, np);
+  if (!active) return;
+  const size_t i = (size_t)gy * a.width + gx;
+  const bool hit = best.prim >= 0;
+  a.prim_id[i] = best.prim;
+  Surface<true> sf = {};
+  if (hit) sf = make_surface<true>(a.sc, ray, best);
+  if (a.t) a.t[i] = hit ? best.t : 0.0;
+  if (a.normal) {
+    a.normal[3 * i] = hit ? sf.n.x : 0.0;
+    a.normal[3 * i + 1] = hit ? sf.n.y : 0.0;
+    a.normal[3 * i + 2] = hit ? sf.n.z : 0.0;
+  }
+  if (a.uv) {
+    a.uv[2 * i] = hit ? sf.u : 0.0;
+    a.uv[2 * i + 1] = hit ? sf.v : 0.0;
+  }
+}

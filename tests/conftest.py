@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+FIXTURES = os.path.join(ROOT, "fixtures")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene"]
+
+
+def scene_path(name):
+    return os.path.join(FIXTURES, "ASCII", f"{name}.txt")
+
+
+@pytest.fixture(scope="session")
+def host_scenes():
+    """name -> HostScene, loaded lazily and kept for the session."""
+    from raytracer_amd import HostScene
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = HostScene(scene_path(name), FIXTURES)
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="session")
+def device_scenes(host_scenes):
+    from raytracer_amd import DeviceScene
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = DeviceScene(host_scenes(name), 0)
+        return cache[name]
+    return get
