@@ -20,7 +20,7 @@ HOST_SRCS := $(HOST)/mirt_math.cpp $(HOST)/scene_loader.cpp $(HOST)/image_io.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.h) include/mirt.h
 
 HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function \
-            -ffp-contract=on -munsafe-fp-atomics -fvisibility=hidden $(EXTRA_HIPFLAGS)
+            -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden $(EXTRA_HIPFLAGS)
 # no FMA contraction on the host: the matrices and boxes computed here are compared bit for bit
 # with the reference's
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra -Iinclude -I$(HOST)
@@ -42,9 +42,9 @@ BUILD := $(LIB)/obj
 
 $(BUILD): | $(LIB)
 	mkdir -p $@
-$(BUILD)/kernels.o: $(CSRC)/kernels.hip $(ENGINE_HDRS) | $(BUILD)
+$(BUILD)/kernels.o: $(CSRC)/kernels.hip $(ENGINE_HDRS) Makefile | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
-$(BUILD)/engine.o: $(CSRC)/engine.cpp $(ENGINE_HDRS) $(HOST)/mirt_math.h | $(BUILD)
+$(BUILD)/engine.o: $(CSRC)/engine.cpp $(ENGINE_HDRS) $(HOST)/mirt_math.h Makefile | $(BUILD)
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
 $(BUILD)/engine_math.o: $(HOST)/mirt_math.cpp $(HOST)/mirt_math.h | $(BUILD)
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<

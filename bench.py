@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + secondary) of the render hot path on
+fixtures/ASCII/Test5.txt at 1920x1080, 16 spp, max-depth 5 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one frame.  With N > 1 each rank renders the interleaved 16x16 tiles it owns from its own
+replica of the scene and the frame is all-gathered (RCCL); the gather is inside the timed region.
+Rank 0 prints one JSON line.  `value` counts the rays all ranks traced per second of the slowest
+rank's wall time, with the scene already resident in HBM.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per ray, fixed record sizes: 2 ray records + 2 hit records + the BVH nodes and
+# primitive records the ray tests (N_node, N_prim are measured by the engine's counters)
+RAY_B, HIT_B, NODE_B, PRIM_B = 64, 32, 64, 128
+HBM_PEAK_GBS = 8000.0
+
+
+def bytes_per_ray(n_node, n_prim):
+    return 2 * RAY_B + 2 * HIT_B + n_node * NODE_B + n_prim * PRIM_B
+
+
+def cpu_baseline(scene_name, width, height, spp, depth, rays_per_sample):
+    """Times the CPU path on a bounded sample of the same workload (rank 0, N = 1 only).
+    Prefers the unmodified reference CLI built by oracle/Makefile (kind "reference"); without it the
+    CPU restatement in oracle/ is timed (kind "port")."""
+    cores = int(os.environ.get("OMP_NUM_THREADS") or min(os.cpu_count() or 1, 16))
+    ref = os.path.join(ROOT, "oracle", "_ref", "raytracer_ref")
+    sample = f"{scene_name} {width}x{height} {spp} spp max-depth {depth} (the bench frame at 1/4 of its pixels)"
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as tmp:
+            env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+            cmd = [ref, "--scene", os.path.join("ASCII", f"{scene_name}.txt"), "--resolution", str(width), str(height),
+                   "--samples", str(spp), "--max-depth", str(depth), "--output", os.path.join(tmp, "cpu.ppm")]
+            r = subprocess.run(cmd, cwd=os.path.join(ROOT, "fixtures"), env=env, capture_output=True, text=True)
+            m = re.search(r"seconds=([0-9.]+)\s+Render time|Render time.*?seconds=([0-9.]+)", r.stdout)
+            if r.returncode == 0 and m:
+                sec = float(m.group(1) or m.group(2))  # the reference's own "Render time" line
+                if sec > 0:
+                    return {"value": width * height * spp * rays_per_sample / sec / 1e6, "unit": "Mrays/s",
+                            "cores": cores, "kind": "reference", "seconds": sec,
+                            "sample": sample + "; ray count = samples x the engine's measured rays per sample"}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        from raytracer_amd import HostScene, default_config
+        hs = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{scene_name}.txt"))
+        cam, _ = hs.camera(0)
+        cfg = default_config(max_ray_depth=depth)
+        t0 = time.perf_counter()
+        _, st = O.render(hs.desc, cam, cfg, width, height, spp, O.RNG_KEYED)
+        sec = time.perf_counter() - t0
+        return {"value": (st["primary_rays"] + st["secondary_rays"]) / sec / 1e6, "unit": "Mrays/s",
+                "cores": O.lib().oracle_max_threads(), "kind": "port", "seconds": sec, "sample": sample}
+    except Exception as e:  # the baseline is informative; never fail the bench on it
+        return {"value": None, "unit": "Mrays/s", "cores": cores, "kind": "unavailable", "sample": str(e)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="Test5")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--soft-shadows", type=int, default=None)
+    ap.add_argument("--glossy-reflection", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import DeviceScene, HostScene, default_config
+    from raytracer_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the engine has no CPU path")
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    hs = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{args.scene}.txt"))
+    ds = DeviceScene(hs, local_rank)
+    cam, _ = hs.camera(0)
+    over = dict(max_ray_depth=args.max_depth, glossy_samples=args.glossy_reflection)
+    if args.soft_shadows is not None:
+        over["shadow_samples"] = args.soft_shadows
+    cfg = default_config(**over)
+    W, H, spp, tile = args.width, args.height, args.spp, D.TILE
+
+    if world > 1:
+        local = D.local_buffer(W, H, tile, tile, world, device)
+    else:
+        local = torch.empty(W * H * 3, dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def step():
+        if world > 1:
+            st = ds.render_tiles(cam, cfg, W, H, spp, tile, tile, rank, world, local.data_ptr(), stream)
+            frame = D.gather_frame(local, W, H, tile, tile)
+        else:
+            st = ds.render_tiles(cam, cfg, W, H, spp, W, H, 0, 1, local.data_ptr(), stream)
+            frame = local.view(H, W, 3)
+        return frame, st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    acc = None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame, st = step()
+        acc = st if acc is None else {k: acc[k] + st[k] for k in st}
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    keys = ["primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
+            "shadow_prim_tests", "trace_kernel_launches", "shadow_kernel_launches"]
+    tot = torch.tensor([float(acc[k]) for k in keys] + [acc["trace_kernel_ms"], acc["shadow_kernel_ms"]],
+                       dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed, acc["trace_kernel_ms"], acc["shadow_kernel_ms"]], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = dict(zip(keys + ["trace_kernel_ms", "shadow_kernel_ms"], tot.tolist()))
+    elapsed = float(tmax[0])
+
+    if rank == 0:
+        steps = args.steps
+        rays_ps = tot["primary_rays"] + tot["secondary_rays"]
+        rays_all = rays_ps + tot["shadow_segments"]
+        # dominant kernel = the kind with the larger summed HIP-event time on this run
+        kinds = {
+            "k_trace": (rays_ps, tot["node_tests"], tot["prim_tests"], tot["trace_kernel_ms"], tot["trace_kernel_launches"]),
+            "k_shadow": (tot["shadow_segments"], tot["shadow_node_tests"], tot["shadow_prim_tests"],
+                         tot["shadow_kernel_ms"], tot["shadow_kernel_launches"]),
+        }
+        name = max(kinds, key=lambda k: kinds[k][3])
+        q, nn, npr, ms, launches = kinds[name]
+        b_ray = bytes_per_ray(nn / max(q, 1), npr / max(q, 1))
+        avg_ms = ms / max(launches, 1)
+        achieved = (q / max(launches, 1)) * b_ray / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "Mrays/s (primary+secondary) at 1920x1080x16spp depth 5",
+            "value": rays_ps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.scene} {W}x{H} {spp}spp max-depth {args.max_depth} motion-blur on"
+                                   + (f" glossy {args.glossy_reflection}" if args.glossy_reflection else "")
+                                   + (f" soft-shadows {args.soft_shadows}" if args.soft_shadows is not None else ""),
+                       "tile": tile if world > 1 else None, "parallelism": f"tiles/{world}"},
+            "mrays_all_per_s": rays_all / elapsed / 1e6,
+            "rays_per_sample": rays_ps / max(tot["primary_rays"], 1),
+            "shadow_segments_per_sample": tot["shadow_segments"] / max(tot["primary_rays"], 1),
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_ray": b_ray, "node_tests_per_ray": nn / max(q, 1),
+                         "prim_tests_per_ray": npr / max(q, 1), "rays_per_launch": q / max(launches, 1),
+                         "avg_launch_ms": avg_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.scene, W // 2, H // 2, spp, args.max_depth, line["rays_per_sample"])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,8 +180,10 @@ typedef struct mirt_stats {
   uint64_t primary_rays;     /* camera samples traced */
   uint64_t secondary_rays;   /* reflection, glossy and refraction rays traced */
   uint64_t shadow_segments;  /* closest-hit queries issued for shadows (Raytracer.cpp:181-203) */
-  uint64_t node_tests;       /* ray/box tests, counted per ray */
-  uint64_t prim_tests;       /* ray/primitive tests, counted per ray (g_intersection_tests, Bvh.cpp:246) */
+  uint64_t node_tests;       /* ray/box tests of the primary and secondary rays, counted per ray */
+  uint64_t prim_tests;       /* their ray/primitive tests (g_intersection_tests, Bvh.cpp:246) */
+  uint64_t shadow_node_tests; /* ray/box tests of the shadow segments */
+  uint64_t shadow_prim_tests; /* ray/primitive tests of the shadow segments */
   uint64_t launches;         /* kernel launches */
   double device_ms;          /* HIP-event time from first launch to last, on the engine's stream */
   double trace_kernel_ms;    /* sum of HIP-event durations of the trace/shade launches */
@@ -232,6 +234,14 @@ int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int tile_h, i
  * may each be NULL. */
 int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int width, int height,
                    int32_t *prim_id, double *t, double *normal, double *uv);
+
+/* Parity hook: closest hit of n caller-supplied rays, i.e.
+ * `intersect_bvh(Ray(origin, dir, time), root, scene, hit, t_min, t_max)` (Bvh.cpp:306) per ray.
+ * origin, dir: 3 doubles per ray (dir is used as given, not normalised); time: per ray, or NULL
+ * for 0.5 (Ray.h:15); t_max: per ray, or NULL for DBL_MAX.  Outputs as in mirt_trace_ids. */
+int mirt_trace_rays(mirt_scene *scene, int64_t n, const double *origin, const double *dir,
+                    const double *time, double t_min, const double *t_max, int32_t *prim_id, double *t,
+                    double *normal);
 
 const char *mirt_last_error(void);
 int mirt_abi_version(void);

@@ -1087,6 +1087,27 @@ int oracle_render(const mirt_scene_desc *sc, const mirt_camera *cam, const mirt_
   return 0;
 }
 
+// intersect_bvh (Bvh.cpp:306) for caller-supplied rays; time / t_max may be NULL (0.5 / DBL_MAX).
+int oracle_trace_rays(const mirt_scene_desc *sc, int64_t n, const double *origin, const double *dir,
+                      const double *time, double t_min, const double *t_max, int32_t *prim_id, double *t,
+                      double *normal) {
+  mirt_config cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < n; i++) {
+    Ctx cx{sc, &cfg, {}, {}};
+    Ray ray(v3(origin + 3 * i), v3(dir + 3 * i), time ? time[i] : 0.5);
+    Hit hit;
+    double tmax = t_max ? t_max[i] : std::numeric_limits<double>::max();
+    const bool ok = hit_bvh(cx, ray, 0, hit, t_min, tmax);
+    prim_id[i] = ok ? hit.prim : -1;
+    if (t) t[i] = ok ? hit.t : 0.0;
+    if (normal)
+      for (int k = 0; k < 3; k++) normal[3 * i + k] = ok ? hit.normal[k] : 0.0;
+  }
+  return 0;
+}
+
 int oracle_max_threads(void);
 }  // extern "C"
 

@@ -76,7 +76,8 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("secondary_rays", C.c_uint64), ("shadow_segments", C.c_uint64),
-                ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("launches", C.c_uint64),
+                ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("shadow_node_tests", C.c_uint64),
+                ("shadow_prim_tests", C.c_uint64), ("launches", C.c_uint64),
                 ("device_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
                 ("trace_kernel_launches", C.c_uint64), ("shadow_kernel_launches", C.c_uint64)]
 
@@ -86,7 +87,7 @@ class Stats(C.Structure):
 
 ENGINE_SYMBOLS = [
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
-    "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_last_error", "mirt_abi_version",
+    "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_last_error", "mirt_abi_version",
 ]
 
 
@@ -105,6 +106,7 @@ def _declare_engine(lib):
     lib.mirt_tile_buffer_pixels.argtypes = [C.c_int] * 6
     lib.mirt_tile_buffer_pixels.restype = C.c_int64
     lib.mirt_trace_ids.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, dp]
+    lib.mirt_trace_rays.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp, C.c_double, dp, C.POINTER(C.c_int32), dp, dp]
     lib.mirt_last_error.restype = C.c_char_p
     lib.mirt_abi_version.restype = C.c_int
     return lib

@@ -140,6 +140,30 @@ class DeviceScene:
                                         nrm.ctypes.data_as(dp), uv.ctypes.data_as(dp)), "mirt_trace_ids")
         return {"prim_id": ids, "t": t, "normal": nrm, "uv": uv}
 
+    def trace_rays(self, origin, direction, time=None, t_min=1e-5, t_max=None):
+        """Closest hit of arbitrary rays (mirt_trace_rays)."""
+        rc, out = _trace_rays(self._lib.mirt_trace_rays, self._h, origin, direction, time, t_min, t_max)
+        _check(rc, "mirt_trace_rays")
+        return out
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _trace_rays(fn, handle, origin, direction, time, t_min, t_max):
+    origin = np.ascontiguousarray(origin, dtype=np.float64).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    n = origin.shape[0]
+    time = None if time is None else np.ascontiguousarray(time, dtype=np.float64)
+    t_max = None if t_max is None else np.ascontiguousarray(t_max, dtype=np.float64)
+    ids = np.empty(n, dtype=np.int32)
+    t = np.empty(n, dtype=np.float64)
+    nrm = np.empty((n, 3), dtype=np.float64)
+    rc = fn(handle, n, _dptr(origin), _dptr(direction), _dptr(time), float(t_min), _dptr(t_max),
+            ids.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(t), _dptr(nrm))
+    return rc, {"prim_id": ids, "t": t, "normal": nrm}
+
 
 def tile_buffer_pixels(width, height, tile_w, tile_h, rank, world):
     return int(A.engine_lib().mirt_tile_buffer_pixels(width, height, tile_w, tile_h, rank, world))

@@ -133,7 +133,8 @@ struct alignas(16) DShadowItem {
 static_assert(sizeof(DShadowItem) == 64, "DShadowItem must be 64 bytes");
 
 struct DCounters {
-  unsigned long long primary, secondary, shadow_segments, node_tests, prim_tests;
+  unsigned long long primary, secondary, shadow_segments, node_tests, prim_tests, shadow_node_tests,
+      shadow_prim_tests;
 };
 
 // ---- kernel argument blocks (passed by value) --------------------------------------------------
@@ -177,6 +178,15 @@ struct IdsArgs {
   double *t, *normal, *uv;
 };
 
+struct RaysArgs {
+  DScene sc;
+  const double *origin, *dir, *time, *t_max;  // 3n, 3n, n or NULL (0.5), n or NULL (DBL_MAX)
+  double t_min;
+  uint32_t n;
+  int32_t *prim_id;
+  double *t, *normal;
+};
+
 // Launchers defined in kernels.hip (the only translation unit compiled for the GPU).
 // uv: the scene samples image maps, so hits carry texture coordinates and a tangent frame;
 // motion: some ray of the launch may be at a shutter time other than 0.5.
@@ -184,3 +194,4 @@ void launch_trace(bool primary, bool uv, bool motion, unsigned grid, void *strea
 void launch_shadow(unsigned grid, void *stream, const ShadowArgs &a);
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a);
 void launch_trace_ids(unsigned grid, void *stream, const IdsArgs &a);
+void launch_trace_rays(unsigned grid, void *stream, const RaysArgs &a);

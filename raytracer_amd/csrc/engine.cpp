@@ -35,6 +35,12 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+#define HIP_CHECKPOINT(label)                                                                     \
+  do {                                                                                             \
+    hipError_t e_ = hipGetLastError();                                                             \
+    if (e_ != hipSuccess) return fail(MIRT_ERR_DEVICE, "HIP error pending at %s: %s", label, hipGetErrorString(e_)); \
+  } while (0)
+
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
     hipError_t e_ = (expr);                                                                        \
@@ -46,6 +52,13 @@ int fail(int code, const char *fmt, ...) {
 struct DeviceBuffer {
   void *p = nullptr;
   size_t bytes = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  DeviceBuffer(DeviceBuffer &&o) noexcept : p(o.p), bytes(o.bytes) {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
   ~DeviceBuffer() { release(); }
   void release() {
     if (p) (void)hipFree(p);
@@ -71,6 +84,16 @@ template <class T> hipError_t upload(DeviceBuffer &b, const std::vector<T> &v) {
 struct RayQueueMem {
   DeviceBuffer mem;
   DRayQueue q{};
+  RayQueueMem() = default;
+  RayQueueMem(RayQueueMem &&o) noexcept : q(o.q) {
+    mem.p = o.mem.p;
+    mem.bytes = o.mem.bytes;
+    o.mem.p = nullptr;
+    o.mem.bytes = 0;
+    o.q = DRayQueue{};
+  }
+  RayQueueMem(const RayQueueMem &) = delete;
+  RayQueueMem &operator=(const RayQueueMem &) = delete;
 };
 
 // which kinds of ray-spawning materials the scene has (decides the most children one hit can have)
@@ -419,7 +442,7 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   } guard{sc};
   sc->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->pinned), 64, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->pinned), 128, hipHostMallocDefault));
 
   const mirt_scene_desc &s = *desc;
   std::vector<DNode> nodes(s.n_nodes);
@@ -530,6 +553,7 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   if (tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world)
     return fail(MIRT_ERR_INVALID, "bad tile split: tile %dx%d rank %d of %d", tile_w, tile_h, rank, world);
   if ((double)width * height * spp > 4.0e9) return fail(MIRT_ERR_UNSUPPORTED, "more than 4e9 samples in one frame");
+  HIP_CHECKPOINT("entry");
   HIP_TRY(hipSetDevice(sc->device));
   if (!stream) stream = sc->stream;
 
@@ -570,6 +594,7 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   }
   if (n_lights) HIP_TRY(hipMemcpyAsync(sc->light_frame.p, lf.data(), sizeof(DLightFrame) * n_lights, hipMemcpyHostToDevice, stream));
   fr.light_frame = sc->light_frame.as<DLightFrame>();
+  HIP_CHECKPOINT("light frame");
 
   // working memory
   const int K = max_children(sc->kinds, config->glossy_samples);
@@ -591,6 +616,7 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   HIP_TRY(sc->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
   const size_t batch_rays = std::min(sc->ray_capacity / K, sc->shadow_capacity / S);  // rays one launch may trace
 
+  HIP_CHECKPOINT("working memory");
   DCounters *counters = sc->counters.as<DCounters>();
   HIP_TRY(hipMemsetAsync(counters, 0, sizeof(DCounters), stream));
   if (n_pixels) HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
@@ -605,6 +631,7 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   HIP_TRY(get_event(sc, ev_used, ev_end));
   HIP_TRY(hipEventRecord(ev_begin, stream));
   uint64_t launches = 0, secondary = 0, primary = 0;
+  HIP_CHECKPOINT("frame begin");
 
   // traces `n` rays of depth `depth` (from the camera when depth == 0, else from queue[depth]
   // starting at `first`), then their shadow work, then -- recursively -- the rays they spawned
@@ -623,7 +650,9 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     int launch(int depth, uint32_t first, uint32_t n_units, uint32_t n_rays_or_blocks) {
       (void)n_units;
       const bool spawn = depth + 1 < fr.cfg.max_ray_depth;
+      HIP_CHECKPOINT("launch entry");
       if (spawn) HIP_TRY(ensure_queue(sc, depth + 1));
+      HIP_CHECKPOINT("ensure_queue");
       TraceArgs a;
       std::memset(&a, 0, sizeof a);
       a.sc = sc->d;
@@ -641,14 +670,25 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
       a.first = first;
       a.n = n_rays_or_blocks;
       a.depth = depth;
+      HIP_CHECKPOINT("queue setup");
       HIP_TRY(hipMemsetAsync(sc->shadow_count, 0, sizeof(uint32_t), stream));
+      HIP_CHECKPOINT("shadow count reset");
       const unsigned grid = depth == 0 ? n_rays_or_blocks * (unsigned)fr.spp : (n_rays_or_blocks + 255u) / 256u;
       Timed t{nullptr, nullptr, 0};
       HIP_TRY(get_event(sc, ev_used, t.a));
       HIP_TRY(get_event(sc, ev_used, t.b));
       HIP_TRY(hipEventRecord(t.a, stream));
-      launch_trace(depth == 0, uv, depth == 0 ? motion : motion, grid, stream, a);
-      HIP_TRY(hipGetLastError());
+      {
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess) return fail(MIRT_ERR_DEVICE, "stale HIP error before trace launch: %s", hipGetErrorString(stale));
+      }
+      launch_trace(depth == 0, uv, motion, grid, stream, a);
+      {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+          return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u, args %zu B): %s", depth, grid, sizeof(TraceArgs),
+                      hipGetErrorString(le));
+      }
       HIP_TRY(hipEventRecord(t.b, stream));
       timed.push_back(t);
       launches++;
@@ -738,6 +778,8 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     stats->shadow_segments = c.shadow_segments;
     stats->node_tests = c.node_tests;
     stats->prim_tests = c.prim_tests;
+    stats->shadow_node_tests = c.shadow_node_tests;
+    stats->shadow_prim_tests = c.shadow_prim_tests;
     stats->launches = launches;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
@@ -811,5 +853,41 @@ MIRT_API int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int wi
   if (t) HIP_TRY(hipMemcpy(t, a.t, n * sizeof(double), hipMemcpyDeviceToHost));
   if (normal) HIP_TRY(hipMemcpy(normal, a.normal, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
   if (uv) HIP_TRY(hipMemcpy(uv, a.uv, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+  return MIRT_OK;
+}
+
+MIRT_API int mirt_trace_rays(mirt_scene *scene, int64_t n, const double *origin, const double *dir, const double *time,
+                             double t_min, const double *t_max, int32_t *prim_id, double *t, double *normal) {
+  if (!scene || !origin || !dir || !prim_id) return fail(MIRT_ERR_INVALID, "NULL argument");
+  if (n < 0 || n > 0x7fffffff) return fail(MIRT_ERR_INVALID, "ray count out of range");
+  if (n == 0) return MIRT_OK;
+  HIP_TRY(hipSetDevice(scene->device));
+  const size_t N = (size_t)n;
+  // layout: origin 3N | dir 3N | time N | t_max N | t N | normal 3N | ids N
+  HIP_TRY(scene->ids.reserve(N * (12 * sizeof(double) + sizeof(int32_t)) + 64));
+  double *base = scene->ids.as<double>();
+  RaysArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.sc = scene->d;
+  double *d_o = base, *d_d = base + 3 * N, *d_time = base + 6 * N, *d_tmax = base + 7 * N;
+  a.t = base + 8 * N;
+  a.normal = base + 9 * N;
+  a.prim_id = reinterpret_cast<int32_t *>(base + 12 * N);
+  HIP_TRY(hipMemcpy(d_o, origin, 3 * N * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_d, dir, 3 * N * sizeof(double), hipMemcpyHostToDevice));
+  if (time) HIP_TRY(hipMemcpy(d_time, time, N * sizeof(double), hipMemcpyHostToDevice));
+  if (t_max) HIP_TRY(hipMemcpy(d_tmax, t_max, N * sizeof(double), hipMemcpyHostToDevice));
+  a.origin = d_o;
+  a.dir = d_d;
+  a.time = time ? d_time : nullptr;
+  a.t_max = t_max ? d_tmax : nullptr;
+  a.t_min = t_min;
+  a.n = (uint32_t)N;
+  launch_trace_rays((unsigned)((N + 255) / 256), scene->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(scene->stream));
+  HIP_TRY(hipMemcpy(prim_id, a.prim_id, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (t) HIP_TRY(hipMemcpy(t, a.t, N * sizeof(double), hipMemcpyDeviceToHost));
+  if (normal) HIP_TRY(hipMemcpy(normal, a.normal, 3 * N * sizeof(double), hipMemcpyDeviceToHost));
   return MIRT_OK;
 }

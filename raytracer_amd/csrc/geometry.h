@@ -10,7 +10,9 @@
 
 #include "device_types.h"
 
+#ifndef DEV
 #define DEV __device__ __forceinline__
+#endif
 
 struct d3 {
   double x, y, z;

@@ -35,3 +35,7 @@ void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a) {
 void launch_trace_ids(unsigned grid, void *stream, const IdsArgs &a) {
   hipLaunchKernelGGL(k_trace_ids, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
 }
+
+void launch_trace_rays(unsigned grid, void *stream, const RaysArgs &a) {
+  hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+}

@@ -552,8 +552,8 @@ __global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
       }
     }
   }
-  count_add(&a.counters->node_tests, n_node);
-  count_add(&a.counters->prim_tests, n_prim);
+  count_add(&a.counters->shadow_node_tests, n_node);
+  count_add(&a.counters->shadow_prim_tests, n_prim);
   count_add(&a.counters->shadow_segments, n_seg);
   if (valid) {
     const double shadow = total * lf.inv_n;
@@ -619,5 +619,32 @@ __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
   if (a.uv) {
     a.uv[2 * i] = hit ? sf.u : 0.0;
     a.uv[2 * i + 1] = hit ? sf.v : 0.0;
+  }
+}
+
+// Closest hit of caller-supplied rays (any origin, direction, shutter time, range): parity hook.
+__global__ __launch_bounds__(256) void k_trace_rays(const RaysArgs a) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool active = i < a.n;
+  const size_t j = active ? i : 0;
+  const RayL ray = make_ray(ld3(a.origin + 3 * j), ld3(a.dir + 3 * j), a.time ? a.time[j] : 0.5);
+  Best<false> best;
+  best.prim = -1;
+  best.t = 0;
+  best.p = mk(0, 0, 0);
+  best.n = mk(0, 0, 1);
+  double closest = a.t_max ? a.t_max[j] : 1.7976931348623157e308;
+  unsigned nn = 0, np = 0;
+  traverse_packet<false, false, true>(a.sc, ray, active, a.t_min, closest, best, nn, np);
+  if (!active) return;
+  const bool hit = best.prim >= 0;
+  a.prim_id[i] = best.prim;
+  if (a.t) a.t[i] = hit ? best.t : 0.0;
+  if (a.normal) {
+    Surface<false> sf = {};
+    if (hit) sf = make_surface<false>(a.sc, ray, best);
+    a.normal[3 * (size_t)i] = sf.n.x;
+    a.normal[3 * (size_t)i + 1] = sf.n.y;
+    a.normal[3 * (size_t)i + 2] = sf.n.z;
   }
 }

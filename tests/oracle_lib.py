@@ -34,6 +34,7 @@ def lib():
                                           dp, dp, ip]
         _lib.oracle_render.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.Camera), C.POINTER(A.Config), C.c_int,
                                        C.c_int, C.c_int, C.c_int, dp, C.POINTER(OracleStats)]
+        _lib.oracle_trace_rays.argtypes = [C.POINTER(A.SceneDesc), C.c_int64, dp, dp, dp, C.c_double, dp, ip, dp, dp]
         _lib.oracle_max_threads.restype = C.c_int
     return _lib
 
@@ -47,6 +48,13 @@ def trace_ids(desc, camera, width, height):
                                 out["t"].ctypes.data_as(dp), out["normal"].ctypes.data_as(dp),
                                 out["uv"].ctypes.data_as(dp), out["point"].ctypes.data_as(dp),
                                 out["front"].ctypes.data_as(ip))
+    assert rc == 0
+    return out
+
+
+def trace_rays(desc, origin, direction, time=None, t_min=1e-5, t_max=None):
+    from raytracer_amd.api import _trace_rays
+    rc, out = _trace_rays(lib().oracle_trace_rays, C.byref(desc), origin, direction, time, t_min, t_max)
     assert rc == 0
     return out
 

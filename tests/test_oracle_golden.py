@@ -1,0 +1,63 @@
+"""The CPU oracle against the golden vectors produced by the reference itself (oracle/_ref/ref_harness,
+see oracle/make_goldens.py).  Everything here is bit-exact: the oracle keeps the reference's order of
+arithmetic and both are built without FMA contraction."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN, SCENES
+from golden_cases import RENDER_CASES
+from raytracer_amd import default_config
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_closest_hit_bit_exact(name, host_scenes):
+    hs = host_scenes(name)
+    gold = np.load(os.path.join(GOLDEN, f"hits_{name}.npz"))
+    w, h = int(gold["width"]), int(gold["height"])
+    cam, _ = hs.camera(0)
+    got = O.trace_ids(hs.desc, cam, w, h)
+    assert np.array_equal(got["prim_id"], gold["prim_id"])
+    assert np.array_equal(got["front"], gold["front"])
+    for k in ("t", "normal", "point", "uv"):
+        assert np.array_equal(got[k], gold[k]), k
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_trace_rgb_bit_exact(name, host_scenes):
+    """Raytracer::trace of pixel-centre rays at depth 5, motion blur off (sequential draws feed the
+    area-light strata of Test6/Test7)."""
+    hs = host_scenes(name)
+    gold = np.load(os.path.join(GOLDEN, f"hits_{name}.npz"))
+    w, h = int(gold["width"]), int(gold["height"])
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=5, enable_motion_blur=0, sampling=1, enable_gamma_correction=0)
+    rgb, _ = O.render(hs.desc, cam, cfg, w, h, 1, O.RNG_SEQUENTIAL)
+    assert np.array_equal(rgb.reshape(-1, 3), gold["trace_rgb_depth5"])
+
+
+@pytest.mark.parametrize("case", sorted(RENDER_CASES))
+def test_stochastic_render_bit_exact(case, host_scenes):
+    """The whole render loop -- jitter, motion-blur time, lens, soft shadows, glossy lobes, glass --
+    with the reference's generators fed the same sequential stream."""
+    scene, dof, over = RENDER_CASES[case]
+    hs = host_scenes(scene)
+    gold = np.load(os.path.join(GOLDEN, f"render_{case}.npz"))
+    w, h, spp = int(gold["width"]), int(gold["height"]), int(gold["spp"])
+    cam, _ = hs.camera(0, dof=dof)
+    cfg = default_config(**over)
+    rgb, st = O.render(hs.desc, cam, cfg, w, h, spp, O.RNG_SEQUENTIAL)
+    assert np.array_equal(rgb.reshape(-1, 3), gold["rgb"])
+    assert st["prim_tests"] == int(gold["prim_tests"])  # g_intersection_tests of the reference
+
+
+def test_keyed_and_sequential_agree_without_randomness(host_scenes):
+    """With nothing random in the frame the two addressings of the random function must coincide."""
+    hs = host_scenes("Test5")
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=4, enable_motion_blur=0, sampling=1)
+    a, _ = O.render(hs.desc, cam, cfg, 48, 27, 1, O.RNG_SEQUENTIAL)
+    b, _ = O.render(hs.desc, cam, cfg, 48, 27, 1, O.RNG_KEYED)
+    assert np.array_equal(a, b)
