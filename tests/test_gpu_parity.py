@@ -48,3 +48,147 @@ def test_deterministic_render_vs_golden(name, host_scenes, device_scenes):
     err = np.abs(got - gold).max()
     print(f"{name}: PSNR {p:.1f} dB, max abs err {err:.3e}, stats {st}")
     assert p >= 80.0  # required: >= 50 dB
+
+
+from golden_cases import RENDER_CASES  # noqa: E402
+from raytracer_amd import DeviceScene, HostScene, scatter_tiles, tile_buffer_pixels  # noqa: E402
+from conftest import scene_path, FIXTURES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", sorted(RENDER_CASES))
+def test_stochastic_render_vs_oracle(case, host_scenes, device_scenes):
+    """Jitter, motion-blur time, lens, soft shadows, glossy lobes, glass: same addressed draws on
+    both sides, so the frames agree to rounding.  Stated bound: PSNR >= 60 dB and mean absolute
+    error <= 1e-6 at equal sample counts (the north star asks for >= 50 dB)."""
+    scene, dof, over = RENDER_CASES[case]
+    hs, ds = host_scenes(scene), device_scenes(scene)
+    gold = np.load(os.path.join(GOLDEN, f"render_{case}.npz"))
+    w, h, spp = int(gold["width"]), int(gold["height"]), int(gold["spp"])
+    cam, _ = hs.camera(0, dof=dof)
+    cfg = default_config(**over)
+    ref, ost = O.render(hs.desc, cam, cfg, w, h, spp, O.RNG_KEYED)
+    got, st = ds.render(cam, cfg, w, h, spp)
+    p, mae = O.psnr(got, ref), float(np.abs(got - ref).mean())
+    print(f"{case}: PSNR {p:.1f} dB, MAE {mae:.3e}, max {np.abs(got - ref).max():.3e}")
+    assert st["primary_rays"] == ost["primary_rays"] == w * h * spp
+    # the ray tree is the oracle's, up to torus silhouettes (the device solves the quartic in double,
+    # the reference in x87 long double): a grazing secondary ray may hit on one side and miss on the other
+    assert abs(st["secondary_rays"] - ost["secondary_rays"]) <= max(2, 1e-3 * ost["secondary_rays"])
+    assert st["shadow_segments"] <= ost["shadow_segments"] * 1.001  # lights behind the surface are not traced
+    assert p >= 60.0 and mae <= 1e-6
+    # against the reference's own frame (sequential draws): same estimator, different samples
+    stat_mae = float(np.abs(np.clip(got, 0, 1).reshape(-1, 3) - np.clip(gold["rgb"], 0, 1)).mean())
+    print(f"{case}: MAE vs the reference's own draws {stat_mae:.4f}")
+    assert stat_mae <= 0.08
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_random_rays_vs_oracle(name, host_scenes, device_scenes):
+    """Rays from anywhere in any direction at any shutter time (inside objects, grazing, from below)."""
+    hs, ds = host_scenes(name), device_scenes(name)
+    rng = np.random.default_rng(11)
+    n = 100000
+    root = hs.desc.nodes[0]
+    lo, hi = np.array(root.bmin[:]), np.array(root.bmax[:])
+    o = lo - 0.1 * (hi - lo) + 1.2 * (hi - lo) * rng.random((n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tm = rng.random(n)
+    ref, got = O.trace_rays(hs.desc, o, d, tm), ds.trace_rays(o, d, tm)
+    # rays that start inside overlapping cubes report the range start for each of them
+    # (Cube.cpp:31-59): an exact tie whose winner is decided by the last bit
+    tie = (ref["t"] < 2e-5) & (ref["prim_id"] >= 0)
+    same = (ref["prim_id"] == got["prim_id"]) | tie
+    print(f"{name}: agreement {same.mean():.6f} over {n} rays, {int((ref['prim_id'] >= 0).sum())} hits")
+    assert same.mean() >= 0.9999
+    ok = (ref["prim_id"] == got["prim_id"]) & (ref["prim_id"] >= 0)
+    assert np.allclose(got["t"][ok], ref["t"][ok], rtol=1e-8, atol=1e-9)
+    assert np.allclose(got["normal"][ok], ref["normal"][ok], atol=1e-6)
+
+
+def test_static_geometry_is_bit_exact(host_scenes, device_scenes):
+    """Distances and normals of every primitive kind but the torus equal the reference's bit for
+    bit (device arithmetic is not contracted into FMAs and keeps the reference's order)."""
+    for name in ("Test1", "Test4", "def_scene"):
+        hs, ds = host_scenes(name), device_scenes(name)
+        cam, _ = hs.camera(0)
+        gold = np.load(os.path.join(GOLDEN, f"hits_{name}.npz"))
+        got = ds.trace_ids(cam, W, H)
+        types = np.array([hs.desc.prims[i].type for i in range(hs.desc.n_prims)])
+        sel = (gold["prim_id"] >= 0) & (types[np.maximum(gold["prim_id"], 0)] != 3)
+        assert np.array_equal(got["t"][sel], gold["t"][sel])
+        assert np.array_equal(got["normal"][sel], gold["normal"][sel])
+
+
+def test_tile_split_equals_whole_frame(host_scenes, device_scenes):
+    hs, ds = host_scenes("Test5"), device_scenes("Test5")
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=4)
+    w, h, spp, tile, world = 100, 70, 2, 16, 3
+    whole, st = ds.render(cam, cfg, w, h, spp)
+    import torch
+    frame = np.zeros((h, w, 3))
+    rays = 0
+    for r in range(world):
+        npx = tile_buffer_pixels(w, h, tile, tile, r, world)
+        buf = torch.full((npx * 3,), -1.0, dtype=torch.float64, device="cuda:0")
+        s = ds.render_tiles(cam, cfg, w, h, spp, tile, tile, r, world, buf.data_ptr())
+        rays += s["primary_rays"] + s["secondary_rays"]
+        scatter_tiles(frame, buf.cpu().numpy(), w, h, tile, tile, r, world)
+    assert rays == st["primary_rays"] + st["secondary_rays"]
+    assert np.allclose(frame, whole, rtol=0, atol=1e-12)  # same rays; only the order of the pixel sums varies
+
+
+def test_edge_cases(host_scenes, device_scenes, tmp_path):
+    hs, ds = host_scenes("Test5"), device_scenes("Test5")
+    cam, _ = hs.camera(0)
+    # depth 0: trace() returns black before touching the scene (Raytracer.cpp:297)
+    img, st = ds.render(cam, default_config(max_ray_depth=0), 16, 9, 1)
+    assert np.array_equal(img, np.zeros((9, 16, 3))) and st["primary_rays"] == 0
+    # one pixel, one sample
+    img, _ = ds.render(cam, default_config(max_ray_depth=3), 1, 1, 1)
+    ref, _ = O.render(hs.desc, cam, default_config(max_ray_depth=3), 1, 1, 1)
+    assert np.allclose(img, ref, atol=1e-9)
+    # a scene without objects or lights renders its background
+    empty = tmp_path / "empty.txt"
+    empty.write_text("SCENE_SETTINGS\nbackground_color 0.25 0.5 1.0\nbackground_strength 0.5\n\nCAMERAS 1\n"
+                     "name c\nlocation 0 0 5\ngaze 0 0 -1\nup 0 1 0\nfocal 35\nsensor 36 24\nresolution 8 8\n")
+    he = HostScene(str(empty), FIXTURES)
+    de = DeviceScene(he, 0)
+    ce, _ = he.camera(0)
+    img, _ = de.render(ce, default_config(enable_gamma_correction=0), 8, 8, 2)
+    assert np.allclose(img, np.broadcast_to([0.125, 0.25, 0.5], (8, 8, 3)), atol=1e-15)
+    # invisible objects stay in the BVH but are never hit (Bvh.cpp:255-278)
+    hv = HostScene(scene_path("Test5"), FIXTURES)
+    for i in range(hv.desc.n_prims):
+        hv.desc.prims[i].visible = 0
+    dv = DeviceScene(hv, 0)
+    assert (dv.trace_ids(cam, 32, 18)["prim_id"] == -1).all()
+    # bad arguments are errors, not crashes
+    from raytracer_amd import MirtError
+    with pytest.raises(MirtError):
+        ds.render(cam, default_config(), 0, 10, 1)
+    with pytest.raises(MirtError):
+        ds.render(cam, default_config(), 10, 10, 0)
+
+
+def test_full_size_properties(host_scenes, device_scenes):
+    """BASELINE config 1 (Test5 1920x1080 16 spp depth 5) at full size, through properties that need
+    no full-size oracle run: ray accounting, repeatability, and agreement of a cropped window with
+    the oracle (the crop is rendered by the oracle through a sub-frame of the same pixel keys)."""
+    hs, ds = host_scenes("Test5"), device_scenes("Test5")
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=5)
+    a, sa = ds.render(cam, cfg, 1920, 1080, 16)
+    b, sb = ds.render(cam, cfg, 1920, 1080, 16)
+    assert sa["primary_rays"] == 1920 * 1080 * 16
+    for k in ("secondary_rays", "shadow_segments", "node_tests", "prim_tests"):
+        assert sa[k] == sb[k]  # the ray tree is deterministic; only float summation order varies
+    assert np.allclose(a, b, rtol=0, atol=1e-12)
+    assert np.isfinite(a).all() and a.min() >= 0.0
+    per_sample = (sa["primary_rays"] + sa["secondary_rays"]) / sa["primary_rays"]
+    assert 1.10 <= per_sample <= 1.18  # the reference measures 1.139 rays per sample on this config
+    # energy sanity against a low-resolution oracle frame of the same view
+    ref, _ = O.render(hs.desc, cam, cfg, 240, 135, 4)
+    small = a.reshape(135, 8, 240, 8, 3).mean(axis=(1, 3))
+    assert abs(np.clip(small, 0, 1).mean() - np.clip(ref, 0, 1).mean()) < 0.01
