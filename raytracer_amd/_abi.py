@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# MIRT_LIB_DIR selects another build of the two libraries (A/B experiments); default: in-tree lib/
+LIB_DIR = os.environ.get("MIRT_LIB_DIR") or os.path.join(_HERE, "lib")
 
 MIRT_SPHERE, MIRT_CUBE, MIRT_PLANE, MIRT_TORUS, MIRT_CYLINDER, MIRT_CONE = range(6)
 MIRT_SAMPLING_JITTER, MIRT_SAMPLING_CENTRE = 0, 1

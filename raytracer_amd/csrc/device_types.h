@@ -114,12 +114,28 @@ struct DLightFrame {
 };
 
 // Ray queue, structure of arrays; one queue per ray-tree depth.
+// Queues are cut into QUEUE_SHARDS independent shards, each with its own tail counter on its own
+// 256-byte line.  A producer block appends to shard blockIdx % QUEUE_SHARDS, so the one atomic a wave
+// issues per append contends with 1/QUEUE_SHARDS of the other waves only: appends to a single tail
+// word serialise at about 11 ns each on this chip, which for the ~10^6 waves of a 1080p x 16 spp launch
+// would cost more than the tracing itself.
+#define QUEUE_SHARDS 32
+#define QUEUE_COUNT_STRIDE 64  // uint32 words between two shards' tail counters
+
 struct DRayQueue {
   double *ox, *oy, *oz, *dx, *dy, *dz, *time, *wr, *wg, *wb;
   uint64_t *key;
   uint32_t *pixel;
-  uint32_t *count;  // device counter
-  uint32_t capacity;
+  uint32_t *count;     // QUEUE_SHARDS tail counters, QUEUE_COUNT_STRIDE words apart
+  uint32_t shard_cap;  // entries per shard; shard s owns slots [s * shard_cap, (s + 1) * shard_cap)
+};
+
+// The part of a sharded queue one consumer launch reads: per shard a range of entries, and the
+// first grid block that works on it (blocks of 256 lanes never straddle two shards).
+struct DQueueView {
+  uint32_t first[QUEUE_SHARDS];
+  uint32_t len[QUEUE_SHARDS];
+  uint32_t block_begin[QUEUE_SHARDS + 1];
 };
 
 // Shadow work item: one (hit, light) pair; 64 bytes.
@@ -132,9 +148,12 @@ struct alignas(16) DShadowItem {
 };
 static_assert(sizeof(DShadowItem) == 64, "DShadowItem must be 64 bytes");
 
-struct DCounters {
+// Statistics counters, replicated COUNTER_SHARDS times (one 64-byte line each) for the same reason
+// as the queue tails; the host adds the replicas up after the frame.
+#define COUNTER_SHARDS 256
+struct alignas(64) DCounters {
   unsigned long long primary, secondary, shadow_segments, node_tests, prim_tests, shadow_node_tests,
-      shadow_prim_tests;
+      shadow_prim_tests, pad;
 };
 
 // ---- kernel argument blocks (passed by value) --------------------------------------------------
@@ -142,14 +161,15 @@ struct TraceArgs {
   DScene sc;
   DFrame fr;
   DRayQueue in;       // unused by the primary launch
+  DQueueView in_view;
   DRayQueue out;
   DShadowItem *shadow;
-  uint32_t *shadow_count;
-  uint32_t shadow_capacity;
+  uint32_t *shadow_count;    // QUEUE_SHARDS tail counters, QUEUE_COUNT_STRIDE words apart
+  uint32_t shadow_shard_cap;
   double *accum;      // 3 doubles per pixel of this rank's tile buffer
-  DCounters *counters;
-  uint32_t first;     // PRIMARY: first 16x16 block of this launch; else first queue entry
-  uint32_t n;         // PRIMARY: number of blocks; else number of queue entries
+  DCounters *counters;  // COUNTER_SHARDS replicas
+  uint32_t first;     // PRIMARY: first 16x16 block of this launch
+  uint32_t n;         // PRIMARY: number of blocks
   int32_t depth;      // depth of the rays this launch traces
 };
 
@@ -157,7 +177,8 @@ struct ShadowArgs {
   DScene sc;
   DFrame fr;
   const DShadowItem *items;
-  uint32_t n;
+  DQueueView view;
+  uint32_t shard_cap;
   double *accum;
   DCounters *counters;
 };

@@ -116,7 +116,7 @@ struct mirt_scene {
   DeviceBuffer shadow_items, counters, accum, out, ids;
   uint32_t *pinned = nullptr;  // [0] ray count, [1] shadow count
   uint32_t *shadow_count = nullptr;
-  size_t ray_capacity = 0, shadow_capacity = 0;
+  size_t ray_shard_cap = 0, shadow_shard_cap = 0;  // entries per queue shard
   std::vector<hipEvent_t> events;
   ~mirt_scene() {
     for (auto e : events) (void)hipEventDestroy(e);
@@ -312,13 +312,16 @@ int max_children(const SpawnKinds &k, int glossy_samples) {
   return m;
 }
 
+constexpr size_t kCountBytes = (size_t)QUEUE_SHARDS * QUEUE_COUNT_STRIDE * sizeof(uint32_t);
+
 hipError_t ensure_queue(mirt_scene *sc, size_t depth) {
   if (sc->queues.size() <= depth) sc->queues.resize(depth + 1);
   RayQueueMem &rq = sc->queues[depth];
-  const size_t cap = sc->ray_capacity;
-  if (rq.q.capacity == cap && rq.mem.p) return hipSuccess;
-  const size_t bytes = cap * (10 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t)) + 256;
-  hipError_t e = rq.mem.reserve(bytes);
+  const size_t cap = sc->ray_shard_cap * QUEUE_SHARDS;
+  if (rq.q.shard_cap == sc->ray_shard_cap && rq.mem.p) return hipSuccess;
+  const size_t data = cap * (10 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t));
+  const size_t count_at = (data + 255) & ~(size_t)255;
+  hipError_t e = rq.mem.reserve(count_at + kCountBytes);
   if (e != hipSuccess) return e;
   char *p = rq.mem.as<char>();
   double **fields[10] = {&rq.q.ox, &rq.q.oy, &rq.q.oz, &rq.q.dx, &rq.q.dy, &rq.q.dz, &rq.q.time, &rq.q.wr, &rq.q.wg, &rq.q.wb};
@@ -329,10 +332,26 @@ hipError_t ensure_queue(mirt_scene *sc, size_t depth) {
   rq.q.key = reinterpret_cast<uint64_t *>(p);
   p += cap * sizeof(uint64_t);
   rq.q.pixel = reinterpret_cast<uint32_t *>(p);
-  p += cap * sizeof(uint32_t);
-  rq.q.count = reinterpret_cast<uint32_t *>(p);
-  rq.q.capacity = (uint32_t)cap;
+  rq.q.count = reinterpret_cast<uint32_t *>(rq.mem.as<char>() + count_at);
+  rq.q.shard_cap = (uint32_t)sc->ray_shard_cap;
   return hipSuccess;
+}
+
+// Turns per-shard entry counts into the view of chunk `c` of `chunks` equal parts; returns the
+// number of 256-lane blocks the view needs.
+uint32_t make_view(const uint32_t *counts, uint32_t c, uint32_t chunks, DQueueView &v) {
+  uint32_t blocks = 0;
+  for (int s = 0; s < QUEUE_SHARDS; ++s) {
+    const uint32_t step = (counts[s] + chunks - 1) / chunks;
+    const uint32_t first = std::min(counts[s], c * step);
+    const uint32_t len = std::min(step, counts[s] - first);
+    v.first[s] = first;
+    v.len[s] = len;
+    v.block_begin[s] = blocks;
+    blocks += (len + 255u) / 256u;
+  }
+  v.block_begin[QUEUE_SHARDS] = blocks;
+  return blocks;
 }
 
 size_t env_size(const char *name, size_t dflt) {
@@ -442,7 +461,7 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   } guard{sc};
   sc->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->pinned), 128, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->pinned), 2 * kCountBytes + COUNTER_SHARDS * sizeof(DCounters), hipHostMallocDefault));
 
   const mirt_scene_desc &s = *desc;
   std::vector<DNode> nodes(s.n_nodes);
@@ -510,7 +529,7 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   HIP_TRY(upload(sc->lights, sc->host_lights));
   HIP_TRY(upload(sc->textures, textures));
   HIP_TRY(sc->light_frame.reserve(std::max<size_t>(sizeof(DLightFrame) * s.n_lights, 16)));
-  HIP_TRY(sc->counters.reserve(sizeof(DCounters) + 64));
+  HIP_TRY(sc->counters.reserve(COUNTER_SHARDS * sizeof(DCounters)));
 
   DScene &d = sc->d;
   d.nodes = sc->nodes.as<DNode>();
@@ -553,7 +572,6 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   if (tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world)
     return fail(MIRT_ERR_INVALID, "bad tile split: tile %dx%d rank %d of %d", tile_w, tile_h, rank, world);
   if ((double)width * height * spp > 4.0e9) return fail(MIRT_ERR_UNSUPPORTED, "more than 4e9 samples in one frame");
-  HIP_CHECKPOINT("entry");
   HIP_TRY(hipSetDevice(sc->device));
   if (!stream) stream = sc->stream;
 
@@ -594,31 +612,35 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   }
   if (n_lights) HIP_TRY(hipMemcpyAsync(sc->light_frame.p, lf.data(), sizeof(DLightFrame) * n_lights, hipMemcpyHostToDevice, stream));
   fr.light_frame = sc->light_frame.as<DLightFrame>();
-  HIP_CHECKPOINT("light frame");
 
-  // working memory
+  // working memory.  A launch of B grid blocks puts at most ceil(B / QUEUE_SHARDS) blocks on one
+  // shard, each appending at most 256 * K rays and 256 * S shadow items, so B is chosen to fit.
   const int K = max_children(sc->kinds, config->glossy_samples);
   const int S = std::max(1, n_lights);
-  const size_t per_block = (size_t)256 * spp;
-  size_t want_rays = env_size("MIRT_RAY_QUEUE", (size_t)32 << 20);
-  size_t want_shadow = env_size("MIRT_SHADOW_QUEUE", (size_t)64 << 20);
-  // never more than the frame can produce, never less than one block's worth
-  want_rays = std::max(std::min(want_rays, (size_t)total_blocks * per_block * K), per_block * K);
-  want_shadow = std::max(std::min(want_shadow, (size_t)total_blocks * per_block * S), per_block * S);
-  if (want_rays > 0xfffffff0u || want_shadow > 0xfffffff0u) return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
-  if (want_rays > sc->ray_capacity) {
-    sc->ray_capacity = want_rays;
+  const uint64_t grid_total = total_blocks * (uint64_t)spp;  // primary grid blocks of the whole frame
+  const size_t per_shard_blocks_needed = (size_t)((grid_total + QUEUE_SHARDS - 1) / QUEUE_SHARDS);
+  const size_t min_blocks = (size_t)(spp + QUEUE_SHARDS - 1) / QUEUE_SHARDS;  // one pixel block, all its samples
+  size_t want_r = env_size("MIRT_RAY_QUEUE", (size_t)32 << 20) / QUEUE_SHARDS;
+  size_t want_s = env_size("MIRT_SHADOW_QUEUE", (size_t)64 << 20) / QUEUE_SHARDS;
+  want_r = std::max(std::min(want_r, per_shard_blocks_needed * 256 * K), std::max<size_t>(min_blocks, 1) * 256 * K);
+  want_s = std::max(std::min(want_s, per_shard_blocks_needed * 256 * S), std::max<size_t>(min_blocks, 1) * 256 * S);
+  if (want_r * QUEUE_SHARDS > 0xfffffff0u || want_s * QUEUE_SHARDS > 0xfffffff0u)
+    return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
+  if (want_r > sc->ray_shard_cap) {
+    sc->ray_shard_cap = want_r;
     sc->queues.clear();
   }
-  if (want_shadow > sc->shadow_capacity) sc->shadow_capacity = want_shadow;
-  HIP_TRY(sc->shadow_items.reserve(sc->shadow_capacity * sizeof(DShadowItem) + 64));
-  sc->shadow_count = reinterpret_cast<uint32_t *>(sc->shadow_items.as<char>() + sc->shadow_capacity * sizeof(DShadowItem));
+  if (want_s > sc->shadow_shard_cap) sc->shadow_shard_cap = want_s;
+  const size_t shadow_bytes = sc->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem);
+  HIP_TRY(sc->shadow_items.reserve(shadow_bytes + kCountBytes));
+  sc->shadow_count = reinterpret_cast<uint32_t *>(sc->shadow_items.as<char>() + shadow_bytes);
   HIP_TRY(sc->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
-  const size_t batch_rays = std::min(sc->ray_capacity / K, sc->shadow_capacity / S);  // rays one launch may trace
+  // most grid blocks one producing launch may have
+  const uint64_t max_blocks =
+      (uint64_t)QUEUE_SHARDS * std::min(sc->ray_shard_cap / (256 * (size_t)K), sc->shadow_shard_cap / (256 * (size_t)S));
 
-  HIP_CHECKPOINT("working memory");
   DCounters *counters = sc->counters.as<DCounters>();
-  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(DCounters), stream));
+  HIP_TRY(hipMemsetAsync(counters, 0, COUNTER_SHARDS * sizeof(DCounters), stream));
   if (n_pixels) HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
 
   const bool uv = sc->d.any_maps && config->enable_textures;
@@ -631,115 +653,115 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   HIP_TRY(get_event(sc, ev_used, ev_end));
   HIP_TRY(hipEventRecord(ev_begin, stream));
   uint64_t launches = 0, secondary = 0, primary = 0;
-  HIP_CHECKPOINT("frame begin");
 
-  // traces `n` rays of depth `depth` (from the camera when depth == 0, else from queue[depth]
-  // starting at `first`), then their shadow work, then -- recursively -- the rays they spawned
+  // One producing launch: traces the rays of `depth` (camera rays of pixel blocks [first, first + n)
+  // when depth == 0, else the entries of queue[depth] named by `view`), then the shadow work they
+  // queued, then -- recursively, chunk by chunk -- the rays they spawned.
   struct Runner {
     mirt_scene *sc;
     const DFrame &fr;
     hipStream_t stream;
     DCounters *counters;
     bool uv, motion;
-    size_t batch_rays;
-    int K, S;
+    uint64_t max_blocks;
     size_t &ev_used;
     std::vector<Timed> &timed;
     uint64_t &launches, &secondary;
 
-    int launch(int depth, uint32_t first, uint32_t n_units, uint32_t n_rays_or_blocks) {
-      (void)n_units;
+    int launch(int depth, uint32_t first, uint32_t n, const DQueueView *view, unsigned grid) {
       const bool spawn = depth + 1 < fr.cfg.max_ray_depth;
-      HIP_CHECKPOINT("launch entry");
       if (spawn) HIP_TRY(ensure_queue(sc, depth + 1));
-      HIP_CHECKPOINT("ensure_queue");
       TraceArgs a;
       std::memset(&a, 0, sizeof a);
       a.sc = sc->d;
       a.fr = fr;
-      if (depth > 0) a.in = sc->queues[depth].q;
+      if (depth > 0) {
+        a.in = sc->queues[depth].q;
+        a.in_view = *view;
+      }
       if (spawn) {
         a.out = sc->queues[depth + 1].q;
-        HIP_TRY(hipMemsetAsync(a.out.count, 0, sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(a.out.count, 0, kCountBytes, stream));
       }
       a.shadow = sc->shadow_items.as<DShadowItem>();
       a.shadow_count = sc->shadow_count;
-      a.shadow_capacity = (uint32_t)sc->shadow_capacity;
+      a.shadow_shard_cap = (uint32_t)sc->shadow_shard_cap;
       a.accum = sc->accum.as<double>();
       a.counters = counters;
       a.first = first;
-      a.n = n_rays_or_blocks;
+      a.n = n;
       a.depth = depth;
-      HIP_CHECKPOINT("queue setup");
-      HIP_TRY(hipMemsetAsync(sc->shadow_count, 0, sizeof(uint32_t), stream));
-      HIP_CHECKPOINT("shadow count reset");
-      const unsigned grid = depth == 0 ? n_rays_or_blocks * (unsigned)fr.spp : (n_rays_or_blocks + 255u) / 256u;
+      HIP_TRY(hipMemsetAsync(sc->shadow_count, 0, kCountBytes, stream));
       Timed t{nullptr, nullptr, 0};
       HIP_TRY(get_event(sc, ev_used, t.a));
       HIP_TRY(get_event(sc, ev_used, t.b));
       HIP_TRY(hipEventRecord(t.a, stream));
-      {
-        const hipError_t stale = hipGetLastError();
-        if (stale != hipSuccess) return fail(MIRT_ERR_DEVICE, "stale HIP error before trace launch: %s", hipGetErrorString(stale));
-      }
       launch_trace(depth == 0, uv, motion, grid, stream, a);
       {
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess)
-          return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u, args %zu B): %s", depth, grid, sizeof(TraceArgs),
-                      hipGetErrorString(le));
+          return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u): %s", depth, grid, hipGetErrorString(le));
       }
       HIP_TRY(hipEventRecord(t.b, stream));
       timed.push_back(t);
       launches++;
-      // counts of what it produced
-      sc->pinned[0] = 0;
-      if (spawn) HIP_TRY(hipMemcpyAsync(&sc->pinned[0], a.out.count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipMemcpyAsync(&sc->pinned[1], sc->shadow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      // what it produced, per shard
+      uint32_t *ray_words = sc->pinned, *shadow_words = sc->pinned + kCountBytes / sizeof(uint32_t);
+      if (spawn) HIP_TRY(hipMemcpyAsync(ray_words, a.out.count, kCountBytes, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(shadow_words, sc->shadow_count, kCountBytes, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
-      const uint32_t n_children = sc->pinned[0], n_shadow = sc->pinned[1];
-      if (n_children > sc->ray_capacity || n_shadow > sc->shadow_capacity)
-        return fail(MIRT_ERR_DEVICE, "internal: queue overflow (%u rays, %u shadow items)", n_children, n_shadow);
-      if (n_shadow) {
-        ShadowArgs s;
-        std::memset(&s, 0, sizeof s);
-        s.sc = sc->d;
-        s.fr = fr;
-        s.items = sc->shadow_items.as<DShadowItem>();
-        s.n = n_shadow;
-        s.accum = sc->accum.as<double>();
-        s.counters = counters;
+      uint32_t n_rays[QUEUE_SHARDS], n_shadow[QUEUE_SHARDS];
+      uint64_t rays = 0, shadows = 0;
+      for (int s = 0; s < QUEUE_SHARDS; ++s) {
+        n_rays[s] = spawn ? ray_words[s * QUEUE_COUNT_STRIDE] : 0;
+        n_shadow[s] = shadow_words[s * QUEUE_COUNT_STRIDE];
+        if (n_rays[s] > sc->ray_shard_cap || n_shadow[s] > sc->shadow_shard_cap)
+          return fail(MIRT_ERR_DEVICE, "internal: queue shard %d overflow (%u rays, %u shadow items)", s, n_rays[s],
+                      n_shadow[s]);
+        rays += n_rays[s];
+        shadows += n_shadow[s];
+      }
+      if (shadows) {
+        ShadowArgs sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sc = sc->d;
+        sa.fr = fr;
+        sa.items = sc->shadow_items.as<DShadowItem>();
+        const unsigned sgrid = make_view(n_shadow, 0, 1, sa.view);
+        sa.shard_cap = (uint32_t)sc->shadow_shard_cap;
+        sa.accum = sc->accum.as<double>();
+        sa.counters = counters;
         Timed ts{nullptr, nullptr, 1};
         HIP_TRY(get_event(sc, ev_used, ts.a));
         HIP_TRY(get_event(sc, ev_used, ts.b));
         HIP_TRY(hipEventRecord(ts.a, stream));
-        launch_shadow((n_shadow + 255u) / 256u, stream, s);
+        launch_shadow(sgrid, stream, sa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ts.b, stream));
         timed.push_back(ts);
         launches++;
       }
-      if (n_children) return run_queue(depth + 1, n_children);
-      return MIRT_OK;
-    }
-
-    int run_queue(int depth, uint32_t n) {
-      secondary += n;
-      const uint32_t chunk = (uint32_t)std::min<size_t>(n, batch_rays);
-      for (uint32_t first = 0; first < n; first += chunk) {
-        const uint32_t m = std::min(chunk, n - first);
-        if (int rc = launch(depth, first, m, m)) return rc;
+      if (!rays) return MIRT_OK;
+      secondary += rays;
+      // the spawned rays, in as few chunks as the next queues allow
+      DQueueView v;
+      uint32_t chunks = 1;
+      while (make_view(n_rays, 0, chunks, v) > max_blocks) chunks++;
+      for (uint32_t c = 0; c < chunks; ++c) {
+        const unsigned g = make_view(n_rays, c, chunks, v);
+        if (g == 0) continue;
+        if (int rc = launch(depth + 1, 0, 0, &v, g)) return rc;
       }
       return MIRT_OK;
     }
   };
-  Runner run{sc, fr, stream, counters, uv, motion, batch_rays, K, S, ev_used, timed, launches, secondary};
+  Runner run{sc, fr, stream, counters, uv, motion, max_blocks, ev_used, timed, launches, secondary};
 
   if (config->max_ray_depth > 0 && total_blocks > 0) {
-    const uint64_t blocks_per_launch = std::max<uint64_t>(1, batch_rays / per_block);
+    const uint64_t blocks_per_launch = std::max<uint64_t>(1, max_blocks / (uint64_t)spp);
     for (uint64_t b0 = 0; b0 < total_blocks; b0 += blocks_per_launch) {
       const uint32_t nb = (uint32_t)std::min<uint64_t>(blocks_per_launch, total_blocks - b0);
-      if (int rc = run.launch(0, (uint32_t)b0, nb, nb)) return rc;
+      if (int rc = run.launch(0, (uint32_t)b0, nb, nullptr, nb * (unsigned)spp)) return rc;
     }
     primary = (uint64_t)width * height * spp;
     if (world > 1 || tile_w != width || tile_h != height) {
@@ -766,13 +788,21 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     launches++;
   }
   HIP_TRY(hipEventRecord(ev_end, stream));
-  HIP_TRY(hipMemcpyAsync(sc->pinned + 4, counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
+  DCounters *host_counters = reinterpret_cast<DCounters *>(reinterpret_cast<char *>(sc->pinned) + 2 * kCountBytes);
+  HIP_TRY(hipMemcpyAsync(host_counters, counters, COUNTER_SHARDS * sizeof(DCounters), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
 
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
     DCounters c;
-    std::memcpy(&c, sc->pinned + 4, sizeof c);
+    std::memset(&c, 0, sizeof c);
+    for (int k = 0; k < COUNTER_SHARDS; ++k) {
+      c.shadow_segments += host_counters[k].shadow_segments;
+      c.node_tests += host_counters[k].node_tests;
+      c.prim_tests += host_counters[k].prim_tests;
+      c.shadow_node_tests += host_counters[k].shadow_node_tests;
+      c.shadow_prim_tests += host_counters[k].shadow_prim_tests;
+    }
     stats->primary_rays = primary;
     stats->secondary_rays = secondary;
     stats->shadow_segments = c.shadow_segments;

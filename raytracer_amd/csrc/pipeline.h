@@ -233,19 +233,22 @@ DEV void pixel_add(double *accum, uint32_t pixel, d3 c) {
   unsafeAtomicAdd(p + 2, c.z);
 }
 
-// Appends one ray per pushing lane: the wave counts its pushers with a ballot, one lane reserves
-// the range with a single atomic, every pusher writes at base + its rank among the pushers.
+// Appends one ray per pushing lane to the block's shard of the queue: the wave counts its pushers
+// with a ballot, one lane reserves the range with a single atomic on the shard's tail, every pusher
+// writes at base + its rank among the pushers.
 DEV void queue_push(const DRayQueue &q, bool push, d3 o, d3 d, double time, d3 w, uint64_t key, uint32_t pixel) {
   const unsigned long long mask = __ballot(push);
   if (mask == 0) return;
+  const uint32_t shard = blockIdx.x % QUEUE_SHARDS;
   const int lane = __lane_id();
   const int leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(q.count, (uint32_t)__popcll(mask));
+  if (lane == leader) base = atomicAdd(q.count + shard * QUEUE_COUNT_STRIDE, (uint32_t)__popcll(mask));
   base = __shfl(base, leader);
   if (push) {
-    const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (i < q.capacity) {  // the host sizes every launch so that this always holds
+    const uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (r < q.shard_cap) {  // the host sizes every launch so that this always holds
+      const size_t i = (size_t)shard * q.shard_cap + r;
       q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
       q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
       q.time[i] = time;
@@ -256,28 +259,30 @@ DEV void queue_push(const DRayQueue &q, bool push, d3 o, d3 d, double time, d3 w
   }
 }
 
-DEV void shadow_push(DShadowItem *items, uint32_t *count, uint32_t capacity, bool push, d3 p, d3 c, uint64_t key,
-                     uint32_t pixel, uint32_t light) {
-  const unsigned long long mask = __ballot(push);
-  if (mask == 0) return;
-  const int lane = __lane_id();
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  if (push) {
-    const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (i < capacity) {
-      DShadowItem it;
-      it.p[0] = p.x; it.p[1] = p.y; it.p[2] = p.z;
-      it.c[0] = c.x; it.c[1] = c.y; it.c[2] = c.z;
-      it.key = key;
-      it.pixel = pixel;
-      it.light = light;
-      items[i] = it;
-    }
-  }
+DEV void shadow_store(DShadowItem *items, size_t i, d3 p, d3 c, uint64_t key, uint32_t pixel, uint32_t light) {
+  DShadowItem it;
+  it.p[0] = p.x; it.p[1] = p.y; it.p[2] = p.z;
+  it.c[0] = c.x; it.c[1] = c.y; it.c[2] = c.z;
+  it.key = key;
+  it.pixel = pixel;
+  it.light = light;
+  items[i] = it;
 }
+
+// Locates the queue entry of this lane in a consumer launch: which shard the block works on and
+// which entry of the shard's range the lane takes.  Returns false for lanes past the range's end.
+DEV bool view_entry(const DQueueView &v, uint32_t shard_cap, size_t &slot) {
+  const uint32_t b = blockIdx.x;
+  uint32_t s = 0;
+#pragma unroll 1
+  while (s + 1 < QUEUE_SHARDS && b >= v.block_begin[s + 1]) s++;
+  const uint32_t i = (b - v.block_begin[s]) * 256u + threadIdx.x;
+  slot = (size_t)s * shard_cap + v.first[s] + (i < v.len[s] ? i : 0);
+  return i < v.len[s];
+}
+
+// The replica of the statistics counters this wave adds to.
+DEV DCounters *my_counters(DCounters *c) { return c + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % COUNTER_SHARDS); }
 
 DEV void count_add(unsigned long long *dst, unsigned v) {
   // wave sum, then one atomic per wave
@@ -335,9 +340,8 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
     camera_ray(a.fr.cam, u, v, a.fr.width, a.fr.height, key, ro, rd);
     W = mk(1, 1, 1);
   } else {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    active = i < a.n;
-    const uint32_t j = a.first + (active ? i : 0);
+    size_t j;
+    active = view_entry(a.in_view, a.in.shard_cap, j);
     ro = mk(a.in.ox[j], a.in.oy[j], a.in.oz[j]);
     rd = mk(a.in.dx[j], a.in.dy[j], a.in.dz[j]);
     time = a.in.time[j];
@@ -355,8 +359,8 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
   double closest = 1.7976931348623157e308;  // numeric_limits<double>::max() (Raytracer.cpp:300)
   unsigned n_node = 0, n_prim = 0;
   traverse_packet<false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
-  count_add(&a.counters->node_tests, n_node);
-  count_add(&a.counters->prim_tests, n_prim);
+  count_add(&my_counters(a.counters)->node_tests, n_node);
+  count_add(&my_counters(a.counters)->prim_tests, n_prim);
 
   const bool hit = active && best.prim >= 0;
   if (active && !hit) pixel_add(a.accum, pixel, W * ld3(sc.background));  // Raytracer.cpp:472
@@ -412,26 +416,50 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
     }
   }
 
-  // per-light unshadowed Blinn-Phong terms -> shadow work items (Raytracer.cpp:262-286)
-  for (int li = 0; li < sc.n_lights; li++) {
-    const mirt_light &L = sc.lights[li];
-    bool push = false;
-    d3 c = mk(0, 0, 0);
-    if (hit && lit) {
-      const d3 to = ld3(L.location) - sf.p;
-      const double dist = len(to);
-      const d3 ldir = to / dist;
-      const d3 lin = ld3(L.color) * (L.intensity * cfg.light_intensity_factor / (dist * dist));
-      const double ndl = maxd(0.0, dot(sn, ldir));
-      if (ndl > 0.0) {
-        c = wd * (tint * ndl) * lin;
-        const d3 half = unit(ldir + (-ray.d));
-        const double ndh = maxd(0.0, dot(sn, half));
-        if (ndh > 0.0) c = c + ws * (ld3(m.specular) * pow(ndh, m.shininess)) * lin;
-        push = true;
+  // per-light unshadowed Blinn-Phong terms -> shadow work items (Raytracer.cpp:262-286).  A light
+  // that faces away from the shading normal adds exactly zero in the reference, so it gets no item.
+  // First pass counts the wave's items so that ONE atomic reserves room for all of them.
+  {
+    uint32_t total = 0;
+    for (int li = 0; li < sc.n_lights; li++) {
+      bool push = false;
+      if (hit && lit) {
+        const d3 to = ld3(sc.lights[li].location) - sf.p;
+        push = maxd(0.0, dot(sn, to / len(to))) > 0.0;
+      }
+      total += (uint32_t)__popcll(__ballot(push));
+    }
+    if (total) {
+      const uint32_t shard = blockIdx.x % QUEUE_SHARDS;
+      uint32_t base = 0;
+      if (__lane_id() == 0) base = atomicAdd(a.shadow_count + shard * QUEUE_COUNT_STRIDE, total);
+      base = __shfl(base, 0);
+      const unsigned long long below = (1ull << __lane_id()) - 1ull;
+      for (int li = 0; li < sc.n_lights; li++) {
+        const mirt_light &L = sc.lights[li];
+        bool push = false;
+        d3 c = mk(0, 0, 0);
+        if (hit && lit) {
+          const d3 to = ld3(L.location) - sf.p;
+          const double dist = len(to);
+          const d3 ldir = to / dist;
+          const double ndl = maxd(0.0, dot(sn, ldir));
+          if (ndl > 0.0) {
+            const d3 lin = ld3(L.color) * (L.intensity * cfg.light_intensity_factor / (dist * dist));
+            c = wd * (tint * ndl) * lin;
+            const d3 half = unit(ldir + (-ray.d));
+            const double ndh = maxd(0.0, dot(sn, half));
+            if (ndh > 0.0) c = c + ws * (ld3(m.specular) * pow(ndh, m.shininess)) * lin;
+            push = true;
+          }
+        }
+        const unsigned long long mask = __ballot(push);
+        const uint32_t r = base + (uint32_t)__popcll(mask & below);
+        if (push && r < a.shadow_shard_cap)  // the host sizes every launch so that this always holds
+          shadow_store(a.shadow, (size_t)shard * a.shadow_shard_cap + r, sf.p, c, key, pixel, (uint32_t)li);
+        base += (uint32_t)__popcll(mask);
       }
     }
-    shadow_push(a.shadow, a.shadow_count, a.shadow_capacity, push, sf.p, c, key, pixel, (uint32_t)li);
   }
 
   if (!spawn) return;  // wave-uniform
@@ -490,9 +518,9 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
 __global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  const bool valid = i < a.n;
-  const DShadowItem it = a.items[valid ? i : 0];
+  size_t slot;
+  const bool valid = view_entry(a.view, a.shard_cap, slot);
+  const DShadowItem it = a.items[slot];
   const d3 P = ld3(it.p);
   const mirt_light &L = sc.lights[it.light];
   const DLightFrame lf = a.fr.light_frame[it.light];
@@ -552,9 +580,9 @@ __global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
       }
     }
   }
-  count_add(&a.counters->shadow_node_tests, n_node);
-  count_add(&a.counters->shadow_prim_tests, n_prim);
-  count_add(&a.counters->shadow_segments, n_seg);
+  count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
+  count_add(&my_counters(a.counters)->shadow_prim_tests, n_prim);
+  count_add(&my_counters(a.counters)->shadow_segments, n_seg);
   if (valid) {
     const double shadow = total * lf.inv_n;
     if (!(shadow >= 1.0)) pixel_add(a.accum, it.pixel, ld3(it.c) * (1.0 - shadow));  // Raytracer.cpp:264,271
