@@ -126,17 +126,13 @@ struct DRayQueue {
   double *ox, *oy, *oz, *dx, *dy, *dz, *time, *wr, *wg, *wb;
   uint64_t *key;
   uint32_t *pixel;
-  uint32_t *count;     // QUEUE_SHARDS tail counters, QUEUE_COUNT_STRIDE words apart
   uint32_t shard_cap;  // entries per shard; shard s owns slots [s * shard_cap, (s + 1) * shard_cap)
+  uint32_t pad;
 };
-
-// The part of a sharded queue one consumer launch reads: per shard a range of entries, and the
-// first grid block that works on it (blocks of 256 lanes never straddle two shards).
-struct DQueueView {
-  uint32_t first[QUEUE_SHARDS];
-  uint32_t len[QUEUE_SHARDS];
-  uint32_t block_begin[QUEUE_SHARDS + 1];
-};
+// A queue's tail counters live apart from its storage (QUEUE_SHARDS words, QUEUE_COUNT_STRIDE apart,
+// one block per launch that fills the queue), so that the host can read all of a frame's counts at
+// once when the frame is over.  Consumer kernels read the counts themselves: no launch waits for
+// the host to learn how much the launch before it produced.
 
 // Shadow work item: one (hit, light) pair; 64 bytes.
 struct alignas(16) DShadowItem {
@@ -160,25 +156,27 @@ struct alignas(64) DCounters {
 struct TraceArgs {
   DScene sc;
   DFrame fr;
-  DRayQueue in;       // unused by the primary launch
-  DQueueView in_view;
+  DRayQueue in;              // unused by the primary launch
+  const uint32_t *in_count;  // tail counters of `in` as its producer left them
   DRayQueue out;
+  uint32_t *out_count;       // NULL when the rays of this depth spawn nothing
   DShadowItem *shadow;
-  uint32_t *shadow_count;    // QUEUE_SHARDS tail counters, QUEUE_COUNT_STRIDE words apart
+  uint32_t *shadow_count;
   uint32_t shadow_shard_cap;
-  double *accum;      // 3 doubles per pixel of this rank's tile buffer
-  DCounters *counters;  // COUNTER_SHARDS replicas
-  uint32_t first;     // PRIMARY: first 16x16 block of this launch
-  uint32_t n;         // PRIMARY: number of blocks
-  int32_t depth;      // depth of the rays this launch traces
+  int32_t depth;             // depth of the rays this launch traces
+  double *accum;             // 3 doubles per pixel of this rank's tile buffer
+  DCounters *counters;       // COUNTER_SHARDS replicas
+  uint32_t first;            // PRIMARY: first 16x16 block of this launch
+  uint32_t n;                // PRIMARY: number of blocks
 };
 
 struct ShadowArgs {
   DScene sc;
   DFrame fr;
   const DShadowItem *items;
-  DQueueView view;
+  const uint32_t *count;
   uint32_t shard_cap;
+  uint32_t pad;
   double *accum;
   DCounters *counters;
 };

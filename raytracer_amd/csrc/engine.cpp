@@ -35,12 +35,6 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
-#define HIP_CHECKPOINT(label)                                                                     \
-  do {                                                                                             \
-    hipError_t e_ = hipGetLastError();                                                             \
-    if (e_ != hipSuccess) return fail(MIRT_ERR_DEVICE, "HIP error pending at %s: %s", label, hipGetErrorString(e_)); \
-  } while (0)
-
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
     hipError_t e_ = (expr);                                                                        \
@@ -112,11 +106,13 @@ struct mirt_scene {
   std::vector<mirt_light> host_lights;
   SpawnKinds kinds;
   // per-frame working memory, grown on demand and kept
-  std::vector<RayQueueMem> queues;  // index = depth of the rays it holds
-  DeviceBuffer shadow_items, counters, accum, out, ids;
-  uint32_t *pinned = nullptr;  // [0] ray count, [1] shadow count
-  uint32_t *shadow_count = nullptr;
+  RayQueueMem queues[2];  // rays of even / odd depth: a depth reads one and appends to the other
+  DeviceBuffer shadow_items, control, counters, accum, out, ids;
+  char *pinned = nullptr;  // read-back of the tail counters and the statistics
+  size_t pinned_bytes = 0;
   size_t ray_shard_cap = 0, shadow_shard_cap = 0;  // entries per queue shard
+  uint64_t split_for = 0;  // frame shape (primary grid blocks, depth, glossy samples) `split` was found for
+  uint32_t split = 1;      // primary launches are cut this many times finer than the queues' sizes suggest
   std::vector<hipEvent_t> events;
   ~mirt_scene() {
     for (auto e : events) (void)hipEventDestroy(e);
@@ -314,14 +310,11 @@ int max_children(const SpawnKinds &k, int glossy_samples) {
 
 constexpr size_t kCountBytes = (size_t)QUEUE_SHARDS * QUEUE_COUNT_STRIDE * sizeof(uint32_t);
 
-hipError_t ensure_queue(mirt_scene *sc, size_t depth) {
-  if (sc->queues.size() <= depth) sc->queues.resize(depth + 1);
-  RayQueueMem &rq = sc->queues[depth];
+hipError_t ensure_queue(mirt_scene *sc, int which) {
+  RayQueueMem &rq = sc->queues[which];
   const size_t cap = sc->ray_shard_cap * QUEUE_SHARDS;
   if (rq.q.shard_cap == sc->ray_shard_cap && rq.mem.p) return hipSuccess;
-  const size_t data = cap * (10 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t));
-  const size_t count_at = (data + 255) & ~(size_t)255;
-  hipError_t e = rq.mem.reserve(count_at + kCountBytes);
+  hipError_t e = rq.mem.reserve(cap * (10 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t)));
   if (e != hipSuccess) return e;
   char *p = rq.mem.as<char>();
   double **fields[10] = {&rq.q.ox, &rq.q.oy, &rq.q.oz, &rq.q.dx, &rq.q.dy, &rq.q.dz, &rq.q.time, &rq.q.wr, &rq.q.wg, &rq.q.wb};
@@ -332,26 +325,18 @@ hipError_t ensure_queue(mirt_scene *sc, size_t depth) {
   rq.q.key = reinterpret_cast<uint64_t *>(p);
   p += cap * sizeof(uint64_t);
   rq.q.pixel = reinterpret_cast<uint32_t *>(p);
-  rq.q.count = reinterpret_cast<uint32_t *>(rq.mem.as<char>() + count_at);
   rq.q.shard_cap = (uint32_t)sc->ray_shard_cap;
   return hipSuccess;
 }
 
-// Turns per-shard entry counts into the view of chunk `c` of `chunks` equal parts; returns the
-// number of 256-lane blocks the view needs.
-uint32_t make_view(const uint32_t *counts, uint32_t c, uint32_t chunks, DQueueView &v) {
-  uint32_t blocks = 0;
-  for (int s = 0; s < QUEUE_SHARDS; ++s) {
-    const uint32_t step = (counts[s] + chunks - 1) / chunks;
-    const uint32_t first = std::min(counts[s], c * step);
-    const uint32_t len = std::min(step, counts[s] - first);
-    v.first[s] = first;
-    v.len[s] = len;
-    v.block_begin[s] = blocks;
-    blocks += (len + 255u) / 256u;
-  }
-  v.block_begin[QUEUE_SHARDS] = blocks;
-  return blocks;
+hipError_t ensure_pinned(mirt_scene *sc, size_t bytes) {
+  if (bytes <= sc->pinned_bytes) return hipSuccess;
+  if (sc->pinned) (void)hipHostFree(sc->pinned);
+  sc->pinned = nullptr;
+  sc->pinned_bytes = 0;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&sc->pinned), bytes, hipHostMallocDefault);
+  if (e == hipSuccess) sc->pinned_bytes = bytes;
+  return e;
 }
 
 size_t env_size(const char *name, size_t dflt) {
@@ -461,7 +446,6 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   } guard{sc};
   sc->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->pinned), 2 * kCountBytes + COUNTER_SHARDS * sizeof(DCounters), hipHostMallocDefault));
 
   const mirt_scene_desc &s = *desc;
   std::vector<DNode> nodes(s.n_nodes);
@@ -613,121 +597,123 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   if (n_lights) HIP_TRY(hipMemcpyAsync(sc->light_frame.p, lf.data(), sizeof(DLightFrame) * n_lights, hipMemcpyHostToDevice, stream));
   fr.light_frame = sc->light_frame.as<DLightFrame>();
 
-  // working memory.  A launch of B grid blocks puts at most ceil(B / QUEUE_SHARDS) blocks on one
-  // shard, each appending at most 256 * K rays and 256 * S shadow items, so B is chosen to fit.
+  // ---- working memory ------------------------------------------------------------------------
+  // A launch of B virtual blocks puts at most ceil(B / QUEUE_SHARDS) of them on one shard, each
+  // appending at most 256 * S shadow items and 256 * K rays.  The shadow queue is sized so that a
+  // primary launch can never overflow it.  The ray queues and the deeper levels are sized for what
+  // scenes do in practice (at most one spawned ray per sample and level on average); a frame that
+  // overflows a shard anyway is detected from the tail counters when it is over and rendered again
+  // with finer primary launches.
+  const int levels = config->max_ray_depth;
   const int K = max_children(sc->kinds, config->glossy_samples);
   const int S = std::max(1, n_lights);
   const uint64_t grid_total = total_blocks * (uint64_t)spp;  // primary grid blocks of the whole frame
-  const size_t per_shard_blocks_needed = (size_t)((grid_total + QUEUE_SHARDS - 1) / QUEUE_SHARDS);
-  const size_t min_blocks = (size_t)(spp + QUEUE_SHARDS - 1) / QUEUE_SHARDS;  // one pixel block, all its samples
+  const size_t shard_blocks = (size_t)((grid_total + QUEUE_SHARDS - 1) / QUEUE_SHARDS);
+  const size_t min_blocks = std::max<size_t>(1, (size_t)(spp + QUEUE_SHARDS - 1) / QUEUE_SHARDS);  // one pixel block, all samples
   size_t want_r = env_size("MIRT_RAY_QUEUE", (size_t)32 << 20) / QUEUE_SHARDS;
-  size_t want_s = env_size("MIRT_SHADOW_QUEUE", (size_t)64 << 20) / QUEUE_SHARDS;
-  want_r = std::max(std::min(want_r, per_shard_blocks_needed * 256 * K), std::max<size_t>(min_blocks, 1) * 256 * K);
-  want_s = std::max(std::min(want_s, per_shard_blocks_needed * 256 * S), std::max<size_t>(min_blocks, 1) * 256 * S);
+  size_t want_s = env_size("MIRT_SHADOW_QUEUE", (size_t)128 << 20) / QUEUE_SHARDS;
+  want_r = std::max(std::min(want_r, shard_blocks * 256 * K), min_blocks * 256 * K);
+  want_s = std::max(std::min(want_s, shard_blocks * 256 * S), min_blocks * 256 * S);
   if (want_r * QUEUE_SHARDS > 0xfffffff0u || want_s * QUEUE_SHARDS > 0xfffffff0u)
     return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
-  if (want_r > sc->ray_shard_cap) {
-    sc->ray_shard_cap = want_r;
-    sc->queues.clear();
-  }
+  if (want_r > sc->ray_shard_cap) sc->ray_shard_cap = want_r;
   if (want_s > sc->shadow_shard_cap) sc->shadow_shard_cap = want_s;
-  const size_t shadow_bytes = sc->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem);
-  HIP_TRY(sc->shadow_items.reserve(shadow_bytes + kCountBytes));
-  sc->shadow_count = reinterpret_cast<uint32_t *>(sc->shadow_items.as<char>() + shadow_bytes);
+  HIP_TRY(sc->shadow_items.reserve(sc->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem)));
   HIP_TRY(sc->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
-  // most grid blocks one producing launch may have
-  const uint64_t max_blocks =
-      (uint64_t)QUEUE_SHARDS * std::min(sc->ray_shard_cap / (256 * (size_t)K), sc->shadow_shard_cap / (256 * (size_t)S));
+  if (levels > 1) {
+    HIP_TRY(ensure_queue(sc, 0));
+    HIP_TRY(ensure_queue(sc, 1));
+  }
+  // grid of the launches that consume a queue: fixed, the blocks stride over the queue
+  const unsigned consumer_grid = (unsigned)std::min<size_t>(
+      env_size("MIRT_CONSUMER_BLOCKS", 4096),
+      (size_t)QUEUE_SHARDS * ((std::max(sc->ray_shard_cap, sc->shadow_shard_cap) + 255) / 256));
 
+  const uint64_t shape = grid_total * 1000003ull + (uint64_t)levels * 1009ull + (uint64_t)config->glossy_samples;
+  if (sc->split_for != shape) {
+    sc->split_for = shape;
+    sc->split = 1;
+  }
   DCounters *counters = sc->counters.as<DCounters>();
-  HIP_TRY(hipMemsetAsync(counters, 0, COUNTER_SHARDS * sizeof(DCounters), stream));
-  if (n_pixels) HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
-
   const bool uv = sc->d.any_maps && config->enable_textures;
   const bool motion = sc->d.any_motion && config->enable_motion_blur && config->sampling == MIRT_SAMPLING_JITTER;
 
   size_t ev_used = 0;
   std::vector<Timed> timed;
   hipEvent_t ev_begin, ev_end;
-  HIP_TRY(get_event(sc, ev_used, ev_begin));
-  HIP_TRY(get_event(sc, ev_used, ev_end));
-  HIP_TRY(hipEventRecord(ev_begin, stream));
   uint64_t launches = 0, secondary = 0, primary = 0;
+  const DCounters *host_counters = nullptr;
 
-  // One producing launch: traces the rays of `depth` (camera rays of pixel blocks [first, first + n)
-  // when depth == 0, else the entries of queue[depth] named by `view`), then the shadow work they
-  // queued, then -- recursively, chunk by chunk -- the rays they spawned.
-  struct Runner {
-    mirt_scene *sc;
-    const DFrame &fr;
-    hipStream_t stream;
-    DCounters *counters;
-    bool uv, motion;
-    uint64_t max_blocks;
-    size_t &ev_used;
-    std::vector<Timed> &timed;
-    uint64_t &launches, &secondary;
+  for (;;) {
+    // pixel blocks per primary launch
+    const uint64_t fit = (uint64_t)QUEUE_SHARDS *
+                         std::min(sc->shadow_shard_cap / (256 * (size_t)S), sc->ray_shard_cap / (size_t)256);
+    const uint64_t per_launch = std::max<uint64_t>(1, fit / (uint64_t)spp / sc->split);
+    const size_t chunks = total_blocks ? (size_t)((total_blocks + per_launch - 1) / per_launch) : 0;
+    // tail counters: per primary launch and level, the rays and the shadow items that level queued
+    const size_t control_bytes = std::max<size_t>(chunks * (size_t)std::max(levels, 0) * 2 * kCountBytes, 64);
+    HIP_TRY(sc->control.reserve(control_bytes));
+    HIP_TRY(ensure_pinned(sc, control_bytes + COUNTER_SHARDS * sizeof(DCounters)));
+    auto tails = [&](size_t chunk, int level, int what) {  // what: 0 rays, 1 shadow items
+      return reinterpret_cast<uint32_t *>(sc->control.as<char>() +
+                                          ((chunk * (size_t)levels + (size_t)level) * 2 + (size_t)what) * kCountBytes);
+    };
 
-    int launch(int depth, uint32_t first, uint32_t n, const DQueueView *view, unsigned grid) {
-      const bool spawn = depth + 1 < fr.cfg.max_ray_depth;
-      if (spawn) HIP_TRY(ensure_queue(sc, depth + 1));
-      TraceArgs a;
-      std::memset(&a, 0, sizeof a);
-      a.sc = sc->d;
-      a.fr = fr;
-      if (depth > 0) {
-        a.in = sc->queues[depth].q;
-        a.in_view = *view;
-      }
-      if (spawn) {
-        a.out = sc->queues[depth + 1].q;
-        HIP_TRY(hipMemsetAsync(a.out.count, 0, kCountBytes, stream));
-      }
-      a.shadow = sc->shadow_items.as<DShadowItem>();
-      a.shadow_count = sc->shadow_count;
-      a.shadow_shard_cap = (uint32_t)sc->shadow_shard_cap;
-      a.accum = sc->accum.as<double>();
-      a.counters = counters;
-      a.first = first;
-      a.n = n;
-      a.depth = depth;
-      HIP_TRY(hipMemsetAsync(sc->shadow_count, 0, kCountBytes, stream));
-      Timed t{nullptr, nullptr, 0};
-      HIP_TRY(get_event(sc, ev_used, t.a));
-      HIP_TRY(get_event(sc, ev_used, t.b));
-      HIP_TRY(hipEventRecord(t.a, stream));
-      launch_trace(depth == 0, uv, motion, grid, stream, a);
-      {
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess)
-          return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u): %s", depth, grid, hipGetErrorString(le));
-      }
-      HIP_TRY(hipEventRecord(t.b, stream));
-      timed.push_back(t);
-      launches++;
-      // what it produced, per shard
-      uint32_t *ray_words = sc->pinned, *shadow_words = sc->pinned + kCountBytes / sizeof(uint32_t);
-      if (spawn) HIP_TRY(hipMemcpyAsync(ray_words, a.out.count, kCountBytes, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipMemcpyAsync(shadow_words, sc->shadow_count, kCountBytes, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      uint32_t n_rays[QUEUE_SHARDS], n_shadow[QUEUE_SHARDS];
-      uint64_t rays = 0, shadows = 0;
-      for (int s = 0; s < QUEUE_SHARDS; ++s) {
-        n_rays[s] = spawn ? ray_words[s * QUEUE_COUNT_STRIDE] : 0;
-        n_shadow[s] = shadow_words[s * QUEUE_COUNT_STRIDE];
-        if (n_rays[s] > sc->ray_shard_cap || n_shadow[s] > sc->shadow_shard_cap)
-          return fail(MIRT_ERR_DEVICE, "internal: queue shard %d overflow (%u rays, %u shadow items)", s, n_rays[s],
-                      n_shadow[s]);
-        rays += n_rays[s];
-        shadows += n_shadow[s];
-      }
-      if (shadows) {
+    ev_used = 0;
+    timed.clear();
+    launches = 0;
+    HIP_TRY(get_event(sc, ev_used, ev_begin));
+    HIP_TRY(get_event(sc, ev_used, ev_end));
+    HIP_TRY(hipEventRecord(ev_begin, stream));
+    HIP_TRY(hipMemsetAsync(counters, 0, COUNTER_SHARDS * sizeof(DCounters), stream));
+    HIP_TRY(hipMemsetAsync(sc->control.p, 0, control_bytes, stream));
+    if (n_pixels) HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
+
+    for (size_t c = 0; c < chunks && levels > 0; ++c) {
+      const uint64_t b0 = c * per_launch;
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(per_launch, total_blocks - b0);
+      for (int depth = 0; depth < levels; ++depth) {
+        const bool spawn = depth + 1 < levels;
+        TraceArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.sc = sc->d;
+        a.fr = fr;
+        if (depth > 0) {
+          a.in = sc->queues[depth & 1].q;
+          a.in_count = tails(c, depth - 1, 0);
+        }
+        if (spawn) {
+          a.out = sc->queues[(depth + 1) & 1].q;
+          a.out_count = tails(c, depth, 0);
+        }
+        a.shadow = sc->shadow_items.as<DShadowItem>();
+        a.shadow_count = tails(c, depth, 1);
+        a.shadow_shard_cap = (uint32_t)sc->shadow_shard_cap;
+        a.accum = sc->accum.as<double>();
+        a.counters = counters;
+        a.first = (uint32_t)b0;
+        a.n = nb;
+        a.depth = depth;
+        Timed t{nullptr, nullptr, 0};
+        HIP_TRY(get_event(sc, ev_used, t.a));
+        HIP_TRY(get_event(sc, ev_used, t.b));
+        HIP_TRY(hipEventRecord(t.a, stream));
+        const unsigned grid = depth == 0 ? nb * (unsigned)spp : consumer_grid;
+        launch_trace(depth == 0, uv, motion, grid, stream, a);
+        {
+          const hipError_t le = hipGetLastError();
+          if (le != hipSuccess)
+            return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u): %s", depth, grid, hipGetErrorString(le));
+        }
+        HIP_TRY(hipEventRecord(t.b, stream));
+        timed.push_back(t);
+
         ShadowArgs sa;
         std::memset(&sa, 0, sizeof sa);
         sa.sc = sc->d;
         sa.fr = fr;
         sa.items = sc->shadow_items.as<DShadowItem>();
-        const unsigned sgrid = make_view(n_shadow, 0, 1, sa.view);
+        sa.count = a.shadow_count;
         sa.shard_cap = (uint32_t)sc->shadow_shard_cap;
         sa.accum = sc->accum.as<double>();
         sa.counters = counters;
@@ -735,34 +721,55 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
         HIP_TRY(get_event(sc, ev_used, ts.a));
         HIP_TRY(get_event(sc, ev_used, ts.b));
         HIP_TRY(hipEventRecord(ts.a, stream));
-        launch_shadow(sgrid, stream, sa);
+        launch_shadow(consumer_grid, stream, sa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ts.b, stream));
         timed.push_back(ts);
-        launches++;
+        launches += 2;
       }
-      if (!rays) return MIRT_OK;
-      secondary += rays;
-      // the spawned rays, in as few chunks as the next queues allow
-      DQueueView v;
-      uint32_t chunks = 1;
-      while (make_view(n_rays, 0, chunks, v) > max_blocks) chunks++;
-      for (uint32_t c = 0; c < chunks; ++c) {
-        const unsigned g = make_view(n_rays, c, chunks, v);
-        if (g == 0) continue;
-        if (int rc = launch(depth + 1, 0, 0, &v, g)) return rc;
-      }
-      return MIRT_OK;
     }
-  };
-  Runner run{sc, fr, stream, counters, uv, motion, max_blocks, ev_used, timed, launches, secondary};
 
-  if (config->max_ray_depth > 0 && total_blocks > 0) {
-    const uint64_t blocks_per_launch = std::max<uint64_t>(1, max_blocks / (uint64_t)spp);
-    for (uint64_t b0 = 0; b0 < total_blocks; b0 += blocks_per_launch) {
-      const uint32_t nb = (uint32_t)std::min<uint64_t>(blocks_per_launch, total_blocks - b0);
-      if (int rc = run.launch(0, (uint32_t)b0, nb, nullptr, nb * (unsigned)spp)) return rc;
+    if (n_pixels) {
+      ResolveArgs r;
+      std::memset(&r, 0, sizeof r);
+      r.accum = sc->accum.as<double>();
+      r.out = d_out;
+      r.n_pixels = (uint32_t)n_pixels;
+      r.spp = spp;
+      r.cfg = *config;
+      launch_resolve((unsigned)((n_pixels + 255) / 256), stream, r);
+      HIP_TRY(hipGetLastError());
+      launches++;
     }
+    HIP_TRY(hipEventRecord(ev_end, stream));
+    HIP_TRY(hipMemcpyAsync(sc->pinned, sc->control.p, control_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(sc->pinned + control_bytes, counters, COUNTER_SHARDS * sizeof(DCounters),
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    host_counters = reinterpret_cast<const DCounters *>(sc->pinned + control_bytes);
+
+    // did every queue shard hold what was appended to it?
+    bool overflow = false;
+    secondary = 0;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(sc->pinned);
+    for (size_t c = 0; c < chunks; ++c)
+      for (int level = 0; level < levels; ++level)
+        for (int s = 0; s < QUEUE_SHARDS; ++s) {
+          const size_t at = ((c * (size_t)levels + (size_t)level) * 2) * (kCountBytes / sizeof(uint32_t)) +
+                            (size_t)s * QUEUE_COUNT_STRIDE;
+          const uint32_t rays = words[at], items = words[at + kCountBytes / sizeof(uint32_t)];
+          if (rays > sc->ray_shard_cap || items > sc->shadow_shard_cap) overflow = true;
+          secondary += rays;
+        }
+    if (!overflow) break;
+    if (per_launch == 1)
+      return fail(MIRT_ERR_MEMORY,
+                  "ray queues too small for this frame even one pixel block at a time; raise MIRT_RAY_QUEUE / "
+                  "MIRT_SHADOW_QUEUE (entries)");
+    sc->split *= 2;  // render the frame again with finer primary launches
+  }
+
+  if (levels > 0 && total_blocks > 0) {
     primary = (uint64_t)width * height * spp;
     if (world > 1 || tile_w != width || tile_h != height) {
       // samples of the pixels this rank owns
@@ -774,23 +781,6 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
       primary = px * spp;
     }
   }
-
-  if (n_pixels) {
-    ResolveArgs r;
-    std::memset(&r, 0, sizeof r);
-    r.accum = sc->accum.as<double>();
-    r.out = d_out;
-    r.n_pixels = (uint32_t)n_pixels;
-    r.spp = spp;
-    r.cfg = *config;
-    launch_resolve((unsigned)((n_pixels + 255) / 256), stream, r);
-    HIP_TRY(hipGetLastError());
-    launches++;
-  }
-  HIP_TRY(hipEventRecord(ev_end, stream));
-  DCounters *host_counters = reinterpret_cast<DCounters *>(reinterpret_cast<char *>(sc->pinned) + 2 * kCountBytes);
-  HIP_TRY(hipMemcpyAsync(host_counters, counters, COUNTER_SHARDS * sizeof(DCounters), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
 
   if (stats) {
     std::memset(stats, 0, sizeof *stats);

@@ -14,11 +14,19 @@
 #define DEV __device__ __forceinline__
 #endif
 
+// Scene records are read through the constant address space: the kernels never write them, and a
+// load at a wave-uniform constant address is always issued on the scalar data path (one fetch per
+// wave, operands in scalar registers), whatever stores the kernel has made before it.
+#define RO __attribute__((address_space(4)))
+typedef const RO double *ro_doubles;
+template <class T> DEV const RO T *rdonly(const T *p) { return (const RO T *)p; }
+
 struct d3 {
   double x, y, z;
 };
 DEV d3 mk(double x, double y, double z) { return d3{x, y, z}; }
 DEV d3 ld3(const double *p) { return d3{p[0], p[1], p[2]}; }
+DEV d3 ld3(ro_doubles p) { return d3{p[0], p[1], p[2]}; }
 DEV d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 DEV d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 DEV d3 operator*(d3 a, d3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
@@ -70,7 +78,7 @@ template <> struct Best<true> {
 // XfS: the static 3x4 pair stored in DPrim::xf.  The pointer is wave-uniform in the packet
 //      traversal, so the 24 values live in scalar registers.
 struct XfS {
-  const double *m;
+  ro_doubles m;
   DEV d3 obj_point(d3 p) const {
     return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
             m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
@@ -96,10 +104,10 @@ struct XfS {
 
 // XfT: constant rotation*scale block, translation interpolated per ray.
 struct XfT {
-  const double *m;     // DMotion::m (9) followed by DMotion::minv (9)
+  ro_doubles m;        // DMotion::m (9) followed by DMotion::minv (9)
   d3 t;
   DEV d3 obj_dir(d3 d) const {
-    const double *i = m + 9;
+    ro_doubles i = m + 9;
     return {i[0] * d.x + i[1] * d.y + i[2] * d.z, i[3] * d.x + i[4] * d.y + i[5] * d.z,
             i[6] * d.x + i[7] * d.y + i[8] * d.z};
   }
@@ -110,7 +118,7 @@ struct XfT {
   }
   DEV d3 world_point(d3 p) const { return world_dir(p) + t; }
   DEV d3 world_normal(d3 n) const {
-    const double *i = m + 9;
+    ro_doubles i = m + 9;
     return {i[0] * n.x + i[3] * n.y + i[6] * n.z, i[1] * n.x + i[4] * n.y + i[7] * n.z,
             i[2] * n.x + i[5] * n.y + i[8] * n.z};
   }
@@ -137,7 +145,7 @@ struct XfG {
 
 // Mat4::interpolate (Transform.cpp:239-256) with the decomposition already done: lerp T and S,
 // slerp or normalised lerp R (Quaternion.h:73-116), compose (Transform.cpp:209-236).
-DEV XfG motion_general(const DMotion &mo, double t) {
+DEV XfG motion_general(const RO DMotion &mo, double t) {
   XfG x;
   x.t = mk(mo.t0[0] + mo.dt[0] * t, mo.t0[1] + mo.dt[1] * t, mo.t0[2] + mo.dt[2] * t);
   x.s = mk(mo.s0[0] + mo.ds[0] * t, mo.s0[1] + mo.ds[1] * t, mo.s0[2] + mo.ds[2] * t);
@@ -228,7 +236,7 @@ DEV void isect_sphere(const X &xf, const RayL &ray, double t_min, double &closes
 
 // ---- cube (Cube.cpp:10-145): the box [-1,1]^3 ----------------------------------------------------
 template <bool SHADOW, bool UV, class X>
-DEV void isect_cube(const X &xf, const double *scale, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+DEV void isect_cube(const X &xf, ro_doubles scale, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                     int prim) {
   const d3 o = xf.obj_point(ray.o), d = xf.obj_dir(ray.d);
   double t_near = t_min, t_far = closest_t;
@@ -284,8 +292,8 @@ DEV void isect_cube(const X &xf, const double *scale, const RayL &ray, double t_
 }
 
 // ---- plane (Plane.cpp:8-132): world-space rectangle, no transform, no motion ---------------------
-DEV void plane_frame(Best<false> &, const double *, d3) {}
-DEV void plane_frame(Best<true> &b, const double *pl, d3 ip) {
+DEV void plane_frame(Best<false> &, ro_doubles, d3) {}
+DEV void plane_frame(Best<true> &b, ro_doubles pl, d3 ip) {
   const d3 e1 = ld3(pl + 12), e2 = ld3(pl + 16);
   const d3 local = ip - ld3(pl);
   b.u = dot(local, e1) / pl[15];
@@ -293,7 +301,7 @@ DEV void plane_frame(Best<true> &b, const double *pl, d3 ip) {
   b.tan = e1;
 }
 template <bool SHADOW, bool UV>
-DEV void isect_plane(const double *pl, int flags, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+DEV void isect_plane(ro_doubles pl, int flags, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                      int prim) {
   const d3 p0 = ld3(pl), n = ld3(pl + 3), lo = ld3(pl + 6), hi = ld3(pl + 9);
   const double denom = dot(n, ray.d);
@@ -385,7 +393,7 @@ DEV int quartic_roots(const double *c, double *s) {  // c[0] + ... + c[4] x^4  (
 }
 
 template <bool SHADOW, bool UV, class X>
-DEV void isect_torus(const X &xf, const double *prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+DEV void isect_torus(const X &xf, ro_doubles prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                      int prim) {
   const d3 o = xf.obj_point(ray.o);
   d3 d = xf.obj_dir(ray.d);
@@ -457,7 +465,7 @@ DEV void isect_torus(const X &xf, const double *prm, const RayL &ray, double t_m
 
 // ---- cylinder (Cylinder.cpp:7-116): side + both caps, strict `<` against the nearest so far --------
 template <bool SHADOW, bool UV, class X>
-DEV void isect_cylinder(const X &xf, const double *prm, const RayL &ray, double t_min, double &closest_t,
+DEV void isect_cylinder(const X &xf, ro_doubles prm, const RayL &ray, double t_min, double &closest_t,
                         Best<UV> &b, int prim) {
   const d3 o = xf.obj_point(ray.o), d = xf.obj_dir(ray.d);
   const double radius = prm[0], depth = prm[1], hd = depth / 2.0;
@@ -531,7 +539,7 @@ DEV void isect_cylinder(const X &xf, const double *prm, const RayL &ray, double 
 
 // ---- cone (Cone.cpp:13-171): apex at +depth/2, base cap at -depth/2 -------------------------------
 template <bool SHADOW, bool UV, class X>
-DEV void isect_cone(const X &xf, const double *prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+DEV void isect_cone(const X &xf, ro_doubles prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                     int prim) {
   const double EPS = 1e-6;
   const d3 o = xf.obj_point(ray.o), d = xf.obj_dir(ray.d);
@@ -644,7 +652,7 @@ DEV void isect_cone(const X &xf, const double *prm, const RayL &ray, double t_mi
 
 // One primitive against one ray, with the transform kind chosen by the (wave-uniform) record.
 template <bool SHADOW, bool UV, bool MOTION, class X>
-DEV void isect_shape(const DPrim &pr, const X &xf, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+DEV void isect_shape(const RO DPrim &pr, const X &xf, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                      int prim) {
   switch (pr.type) {
     case MIRT_SPHERE: isect_sphere<SHADOW, UV>(xf, ray, t_min, closest_t, b, prim); break;
@@ -659,7 +667,7 @@ DEV void isect_shape(const DPrim &pr, const X &xf, const RayL &ray, double t_min
 // intersect_obj (Bvh.cpp:244-304) for one ray.  MOTION = false compiles the kernels used when
 // every ray of the launch is at shutter time 0.5 (shadow rays, motion blur off).
 template <bool SHADOW, bool UV, bool MOTION>
-DEV void isect_prim(const DScene &sc, const DPrim &pr, int prim, const RayL &ray, double t_min, double &closest_t,
+DEV void isect_prim(const DScene &sc, const RO DPrim &pr, int prim, const RayL &ray, double t_min, double &closest_t,
                     Best<UV> &b) {
   if (!pr.visible) return;
   if (pr.type == MIRT_PLANE) {
@@ -667,7 +675,7 @@ DEV void isect_prim(const DScene &sc, const DPrim &pr, int prim, const RayL &ray
     return;
   }
   if (MOTION && pr.motion != MOTION_NONE) {
-    const DMotion &mo = sc.motion[pr.motion_index];
+    const RO DMotion &mo = rdonly(sc.motion)[pr.motion_index];
     if (pr.motion == MOTION_TRANSLATE) {
       XfT xf;
       xf.m = mo.m;

@@ -28,11 +28,46 @@
 
 #define WAVE 64
 
+// Register budget of the two big kernels, as waves per SIMD the compiler must make room for.
+#ifndef MIRT_TRACE_WAVES
+#define MIRT_TRACE_WAVES 2
+#endif
+#ifndef MIRT_SHADOW_WAVES
+#define MIRT_SHADOW_WAVES 2
+#endif
+#define WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+// Development aid: -DMIRT_PROFILE=1 (trace kernel) or =2 (shadow kernel) replaces the statistics
+// counters by shader-clock cycles per wave spent in the kernel's sections.
+#ifdef MIRT_PROFILE
+#define PROF_DECL unsigned long long prof_t[6] = {0, 0, 0, 0, 0, 0}, prof_last = clock64()
+#define PROF_MARK(i)                         \
+  do {                                       \
+    const unsigned long long now_ = clock64(); \
+    prof_t[i] += now_ - prof_last;           \
+    prof_last = now_;                        \
+  } while (0)
+#define PROF_FLUSH(c)                                                       \
+  do {                                                                      \
+    if (__lane_id() == 0) {                                                 \
+      atomicAdd(&(c)->node_tests, prof_t[0]);                               \
+      atomicAdd(&(c)->prim_tests, prof_t[1]);                               \
+      atomicAdd(&(c)->shadow_node_tests, prof_t[2]);                        \
+      atomicAdd(&(c)->shadow_prim_tests, prof_t[3]);                        \
+      atomicAdd(&(c)->shadow_segments, prof_t[4]);                          \
+    }                                                                       \
+  } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH(c)
+#endif
+
 DEV double maxd(double a, double b) { return (a < b) ? b : a; }  // std::max(a, b)
 DEV double mind(double a, double b) { return (b < a) ? b : a; }  // std::min(a, b)
 
 // BoundingBox::intersect (BoundingBox.h:14-31), NaN behaviour of std::max / std::min included.
-DEV bool box_hit(const DNode &n, const RayL &r, double t_min, double t_max) {
+DEV bool box_hit(const RO DNode &n, const RayL &r, double t_min, double t_max) {
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const double inv = comp(r.inv, a), o = comp(r.o, a);
@@ -60,7 +95,7 @@ DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double 
   int node = 0;
   while (node < n_nodes) {
     const int un = __builtin_amdgcn_readfirstlane(node);
-    const DNode &nd = sc.nodes[un];
+    const RO DNode &nd = rdonly(sc.nodes)[un];
     const bool on = resume <= un;
     bool hit = false;
     if (on) {
@@ -74,8 +109,8 @@ DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double 
     }
     if (nd.first >= 0) {
       for (int k = 0; k < nd.count; k++) {
-        const int pi = __builtin_amdgcn_readfirstlane(sc.leaf_prims[nd.first + k]);
-        const DPrim &pr = sc.prims[pi];
+        const int pi = rdonly(sc.leaf_prims)[nd.first + k];
+        const RO DPrim &pr = rdonly(sc.prims)[pi];
         if (hit) {
           n_prim++;
           isect_prim<SHADOW, UV, MOTION>(sc, pr, pi, ray, t_min, closest_t, best);
@@ -210,7 +245,7 @@ DEV void camera_ray(const DCamera &c, double x, double y, int width, int height,
 }
 
 // Light::sample_point (Light.h:38-69)
-DEV d3 light_point(const mirt_light &l, double u, double v) {
+template <class L> DEV d3 light_point(const L &l, double u, double v) {
   if (l.type != MIRT_LIGHT_AREA) return ld3(l.location);
   d3 n = ld3(l.normal);
   if (len2(n) < 0.1) n = mk(0, 0, -1);
@@ -236,18 +271,18 @@ DEV void pixel_add(double *accum, uint32_t pixel, d3 c) {
 // Appends one ray per pushing lane to the block's shard of the queue: the wave counts its pushers
 // with a ballot, one lane reserves the range with a single atomic on the shard's tail, every pusher
 // writes at base + its rank among the pushers.
-DEV void queue_push(const DRayQueue &q, bool push, d3 o, d3 d, double time, d3 w, uint64_t key, uint32_t pixel) {
+DEV void queue_push(const DRayQueue &q, uint32_t *count, uint32_t shard, bool push, d3 o, d3 d, double time, d3 w,
+                    uint64_t key, uint32_t pixel) {
   const unsigned long long mask = __ballot(push);
   if (mask == 0) return;
-  const uint32_t shard = blockIdx.x % QUEUE_SHARDS;
   const int lane = __lane_id();
   const int leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(q.count + shard * QUEUE_COUNT_STRIDE, (uint32_t)__popcll(mask));
+  if (lane == leader) base = atomicAdd(count + shard * QUEUE_COUNT_STRIDE, (uint32_t)__popcll(mask));
   base = __shfl(base, leader);
   if (push) {
     const uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (r < q.shard_cap) {  // the host sizes every launch so that this always holds
+    if (r < q.shard_cap) {  // a full shard drops the ray; the host sees the tail past the capacity and redoes the frame
       const size_t i = (size_t)shard * q.shard_cap + r;
       q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
       q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
@@ -269,16 +304,40 @@ DEV void shadow_store(DShadowItem *items, size_t i, d3 p, d3 c, uint64_t key, ui
   items[i] = it;
 }
 
-// Locates the queue entry of this lane in a consumer launch: which shard the block works on and
-// which entry of the shard's range the lane takes.  Returns false for lanes past the range's end.
-DEV bool view_entry(const DQueueView &v, uint32_t shard_cap, size_t &slot) {
-  const uint32_t b = blockIdx.x;
-  uint32_t s = 0;
-#pragma unroll 1
-  while (s + 1 < QUEUE_SHARDS && b >= v.block_begin[s + 1]) s++;
-  const uint32_t i = (b - v.block_begin[s]) * 256u + threadIdx.x;
-  slot = (size_t)s * shard_cap + v.first[s] + (i < v.len[s] ? i : 0);
-  return i < v.len[s];
+// A consumer's view of a sharded queue, held across the lanes of a wave: lane s < QUEUE_SHARDS knows
+// shard s's entry count and the first virtual block (256 entries, never straddling two shards) that
+// works on it.  Every wave of the grid derives the same view from the producer's tail counters.
+struct WaveView {
+  uint32_t begin, blocks, len;
+  uint32_t total;  // virtual blocks over all shards (wave-uniform)
+};
+DEV WaveView wave_view(const uint32_t *count, uint32_t shard_cap) {
+  const int lane = __lane_id();
+  WaveView v;
+  v.len = 0;
+  if (lane < QUEUE_SHARDS) {
+    const uint32_t c = count[lane * QUEUE_COUNT_STRIDE];
+    v.len = c < shard_cap ? c : shard_cap;
+  }
+  v.blocks = (v.len + 255u) >> 8;
+  uint32_t incl = v.blocks;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  v.begin = incl - v.blocks;
+  v.total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+  return v;
+}
+// The entry lane `threadIdx.x` of virtual block `vb` works on; false for lanes past the shard's end.
+DEV bool view_entry(const WaveView &v, uint32_t vb, uint32_t shard_cap, size_t &slot) {
+  const unsigned long long m = __ballot(vb >= v.begin && vb < v.begin + v.blocks);
+  const int s = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+  const uint32_t begin = __builtin_amdgcn_readlane(v.begin, s), len = __builtin_amdgcn_readlane(v.len, s);
+  const uint32_t i = (vb - begin) * 256u + threadIdx.x;
+  slot = (size_t)s * shard_cap + (i < len ? i : 0);
+  return i < len;
 }
 
 // The replica of the statistics counters this wave adds to.
@@ -310,18 +369,22 @@ DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int 
   return lx < fr.tile_w && ly < fr.tile_h && gx < fr.width && gy < fr.height;
 }
 
+// One block of 256 rays: virtual block `vb` of the launch.  `active` and `j` locate the lane's queue
+// entry (unused by PRIMARY, whose virtual blocks are (16x16 pixel block, sample index) pairs).
 template <bool PRIMARY, bool UV, bool MOTION>
-__global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
+DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, unsigned &n_node, unsigned &n_prim) {
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
-  bool active;
+  const uint32_t shard = vb % QUEUE_SHARDS;  // of the two queues this block appends to
+#if MIRT_PROFILE == 1
+  PROF_DECL;
+#endif
   d3 ro, rd, W;
   double time;
   uint64_t key;
   uint32_t pixel;
   if (PRIMARY) {
-    // grid: (block, sample) pairs; 256 threads = one 16x16 pixel block at one sample index
-    const uint32_t bs = blockIdx.x;
+    const uint32_t bs = vb;
     const uint32_t block = a.first + bs / (uint32_t)a.fr.spp;
     const uint32_t s = bs % (uint32_t)a.fr.spp;
     int gx, gy;
@@ -340,8 +403,6 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
     camera_ray(a.fr.cam, u, v, a.fr.width, a.fr.height, key, ro, rd);
     W = mk(1, 1, 1);
   } else {
-    size_t j;
-    active = view_entry(a.in_view, a.in.shard_cap, j);
     ro = mk(a.in.ox[j], a.in.oy[j], a.in.oz[j]);
     rd = mk(a.in.dx[j], a.in.dy[j], a.in.dz[j]);
     time = a.in.time[j];
@@ -357,10 +418,13 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
   best.p = mk(0, 0, 0);
   best.n = mk(0, 0, 1);
   double closest = 1.7976931348623157e308;  // numeric_limits<double>::max() (Raytracer.cpp:300)
-  unsigned n_node = 0, n_prim = 0;
+#if MIRT_PROFILE == 1
+  PROF_MARK(0);
+#endif
   traverse_packet<false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
-  count_add(&my_counters(a.counters)->node_tests, n_node);
-  count_add(&my_counters(a.counters)->prim_tests, n_prim);
+#if MIRT_PROFILE == 1
+  PROF_MARK(1);
+#endif
 
   const bool hit = active && best.prim >= 0;
   if (active && !hit) pixel_add(a.accum, pixel, W * ld3(sc.background));  // Raytracer.cpp:472
@@ -416,6 +480,9 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
     }
   }
 
+#if MIRT_PROFILE == 1
+  PROF_MARK(2);
+#endif
   // per-light unshadowed Blinn-Phong terms -> shadow work items (Raytracer.cpp:262-286).  A light
   // that faces away from the shading normal adds exactly zero in the reference, so it gets no item.
   // First pass counts the wave's items so that ONE atomic reserves room for all of them.
@@ -424,19 +491,18 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
     for (int li = 0; li < sc.n_lights; li++) {
       bool push = false;
       if (hit && lit) {
-        const d3 to = ld3(sc.lights[li].location) - sf.p;
+        const d3 to = ld3(rdonly(sc.lights)[li].location) - sf.p;
         push = maxd(0.0, dot(sn, to / len(to))) > 0.0;
       }
       total += (uint32_t)__popcll(__ballot(push));
     }
     if (total) {
-      const uint32_t shard = blockIdx.x % QUEUE_SHARDS;
       uint32_t base = 0;
       if (__lane_id() == 0) base = atomicAdd(a.shadow_count + shard * QUEUE_COUNT_STRIDE, total);
       base = __shfl(base, 0);
       const unsigned long long below = (1ull << __lane_id()) - 1ull;
       for (int li = 0; li < sc.n_lights; li++) {
-        const mirt_light &L = sc.lights[li];
+        const RO mirt_light &L = rdonly(sc.lights)[li];
         bool push = false;
         d3 c = mk(0, 0, 0);
         if (hit && lit) {
@@ -455,13 +521,17 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
         }
         const unsigned long long mask = __ballot(push);
         const uint32_t r = base + (uint32_t)__popcll(mask & below);
-        if (push && r < a.shadow_shard_cap)  // the host sizes every launch so that this always holds
+        if (push && r < a.shadow_shard_cap)  // a full shard drops the item; the host redoes the frame
           shadow_store(a.shadow, (size_t)shard * a.shadow_shard_cap + r, sf.p, c, key, pixel, (uint32_t)li);
         base += (uint32_t)__popcll(mask);
       }
     }
   }
 
+#if MIRT_PROFILE == 1
+  PROF_MARK(3);
+  if (!spawn) PROF_FLUSH(my_counters(a.counters));
+#endif
   if (!spawn) return;  // wave-uniform
 
   // ---- reflection (Raytracer.cpp:317-411); dropped when the glass branch returns `combined` ----
@@ -475,7 +545,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
     d3 cw = ws * R;
     if (metal) cw = cw * tint;
     const d3 org = sf.p + sf.n * eps;
-    queue_push(a.out, refl && mirror, org, r, time, cw, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY), pixel);
+    queue_push(a.out, a.out_count, shard, refl && mirror, org, r, time, cw, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY), pixel);
     const bool lobe = refl && !mirror;
     if (__any(lobe)) {
       const d3 w = r;
@@ -493,7 +563,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
         sincos(2.0 * M_PI * r2, &sp, &cp);
         d3 dir = unit(u * (st * cp) + v * (st * sp) + w * ct);
         if (dot(dir, sf.n) < 0) dir = r;
-        queue_push(a.out, on, org, dir, time, cws, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY + i), pixel);
+        queue_push(a.out, a.out_count, shard, on, org, dir, time, cws, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY + i), pixel);
       }
     }
   }
@@ -502,12 +572,37 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
     const bool g = hit && glass;
     const d3 wbase = pass ? W : W * T;
     const d3 wr = tir ? wbase : wbase * fres;
-    queue_push(a.out, g, sf.p + sf.n * eps, reflect_dir(ray.d, sf.n), time, wr,
+    queue_push(a.out, a.out_count, shard, g, sf.p + sf.n * eps, reflect_dir(ray.d, sf.n), time, wr,
                mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFLECT), pixel);
     const d3 para = sf.n * (-sqrt(maxd(0.0, disc)));
-    queue_push(a.out, g && !tir, sf.p - sf.n * eps, perp + para, time, wbase * (1.0 - fres),
+    queue_push(a.out, a.out_count, shard, g && !tir, sf.p - sf.n * eps, perp + para, time, wbase * (1.0 - fres),
                mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFRACT), pixel);
   }
+#if MIRT_PROFILE == 1
+  PROF_MARK(4);
+  PROF_FLUSH(my_counters(a.counters));
+#endif
+}
+
+// PRIMARY: one grid block per (pixel block, sample).  Otherwise the grid has a fixed size and its
+// blocks stride over the virtual blocks of the input queue, whose length only the device knows.
+template <bool PRIMARY, bool UV, bool MOTION>
+__global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
+  unsigned n_node = 0, n_prim = 0;
+  if (PRIMARY) {
+    trace_block<true, UV, MOTION>(a, blockIdx.x, true, 0, n_node, n_prim);
+  } else {
+    const WaveView v = wave_view(a.in_count, a.in.shard_cap);
+    for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
+      size_t j;
+      const bool active = view_entry(v, vb, a.in.shard_cap, j);
+      trace_block<false, UV, MOTION>(a, vb, active, j, n_node, n_prim);
+    }
+  }
+#ifndef MIRT_PROFILE
+  count_add(&my_counters(a.counters)->node_tests, n_node);
+  count_add(&my_counters(a.counters)->prim_tests, n_prim);
+#endif
 }
 
 
@@ -515,11 +610,13 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a) {
 // is a small state machine -- stratum index, distance walked, attenuation -- and the wave runs
 // closest-hit segments until every lane is done, so lanes with many strata or glass on the way do
 // not hold the others idle between their segments.  Shadow rays are at shutter time 0.5 (Ray.h:15).
-__global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
+DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_node, unsigned &n_prim,
+                      unsigned &n_seg) {
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
-  size_t slot;
-  const bool valid = view_entry(a.view, a.shard_cap, slot);
+#if MIRT_PROFILE == 2
+  PROF_DECL;
+#endif
   const DShadowItem it = a.items[slot];
   const d3 P = ld3(it.p);
   const mirt_light &L = sc.lights[it.light];
@@ -550,8 +647,10 @@ __global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
     return false;
   };
   if (valid) busy = next_stratum();
+#if MIRT_PROFILE == 2
+  PROF_MARK(0);
+#endif
 
-  unsigned n_node = 0, n_prim = 0, n_seg = 0;
   while (__any(busy)) {
     const RayL ray = make_ray(P + dir * cur, dir, 0.5);
     double closest = dist - cur;
@@ -559,7 +658,13 @@ __global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
     best.prim = -1;
     best.t = 0;
     if (busy) n_seg++;
+#if MIRT_PROFILE == 2
+    PROF_MARK(2);
+#endif
     traverse_packet<true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+#if MIRT_PROFILE == 2
+    PROF_MARK(1);
+#endif
     if (busy) {
       bool done = true;
       if (best.prim >= 0 && best.t < (dist - cur)) {
@@ -580,13 +685,30 @@ __global__ __launch_bounds__(256) void k_shadow(const ShadowArgs a) {
       }
     }
   }
-  count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
-  count_add(&my_counters(a.counters)->shadow_prim_tests, n_prim);
-  count_add(&my_counters(a.counters)->shadow_segments, n_seg);
   if (valid) {
     const double shadow = total * lf.inv_n;
     if (!(shadow >= 1.0)) pixel_add(a.accum, it.pixel, ld3(it.c) * (1.0 - shadow));  // Raytracer.cpp:264,271
   }
+#if MIRT_PROFILE == 2
+  PROF_MARK(3);
+  PROF_FLUSH(my_counters(a.counters));
+#endif
+}
+
+// Fixed-size grid striding over the virtual blocks of the shadow queue.
+__global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
+  unsigned n_node = 0, n_prim = 0, n_seg = 0;
+  const WaveView v = wave_view(a.count, a.shard_cap);
+  for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
+    size_t slot;
+    const bool valid = view_entry(v, vb, a.shard_cap, slot);
+    shadow_block(a, valid, slot, n_node, n_prim, n_seg);
+  }
+#ifndef MIRT_PROFILE
+  count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
+  count_add(&my_counters(a.counters)->shadow_prim_tests, n_prim);
+  count_add(&my_counters(a.counters)->shadow_segments, n_seg);
+#endif
 }
 
 
