@@ -57,22 +57,43 @@ DEV RayL make_ray(d3 o, d3 d, double time) {
   return r;
 }
 
-// Closest hit so far of one ray.
-template <bool UV> struct Best;
-template <> struct Best<false> {
+// Closest hit so far of one ray.  Distance and primitive stay in registers; what is only read
+// when the traversal is over (point, normal, texture coordinates, tangent) is written straight to
+// a per-lane record in LDS, so that it does not occupy vector registers while the intersectors run.
+#define LDS_AS __attribute__((address_space(3)))
+#define HIT_STRIDE 256  // doubles between two fields of a lane's record = threads per block
+#define HIT_FIELDS(UV) ((UV) ? 11 : 6)
+template <bool UV> struct Best {
   double t;
-  d3 p;      // world hit point
-  d3 n;      // outward world normal before normalisation (planes: already unit)
-  int prim;  // -1: none
+  int prim;            // -1: none
+  LDS_AS double *rec;  // field k at rec[k * HIT_STRIDE]: p 0-2, n 3-5, u 6, v 7, tan 8-10
+  DEV void put3(int k, d3 v) const {
+    rec[k * HIT_STRIDE] = v.x;
+    rec[(k + 1) * HIT_STRIDE] = v.y;
+    rec[(k + 2) * HIT_STRIDE] = v.z;
+  }
+  DEV d3 get3(int k) const { return d3{rec[k * HIT_STRIDE], rec[(k + 1) * HIT_STRIDE], rec[(k + 2) * HIT_STRIDE]}; }
+  // world hit point; outward world normal before normalisation (planes: already unit)
+  DEV void set_p(d3 v) const { put3(0, v); }
+  DEV void set_n(d3 v) const { put3(3, v); }
+  DEV d3 p() const { return get3(0); }
+  DEV d3 n() const { return get3(3); }
+  // texture coordinates; object-space tangent mapped to world, un-normalised (planes: the unit edge direction)
+  DEV void set_uv(double u, double v) const {
+    rec[6 * HIT_STRIDE] = u;
+    rec[7 * HIT_STRIDE] = v;
+  }
+  DEV void set_tan(d3 v) const { put3(8, v); }
+  DEV double u() const { return rec[6 * HIT_STRIDE]; }
+  DEV double v() const { return rec[7 * HIT_STRIDE]; }
+  DEV d3 tan() const { return get3(8); }
 };
-template <> struct Best<true> {
-  double t;
-  d3 p;
-  d3 n;
-  int prim;
-  double u, v;
-  d3 tan;  // object-space tangent mapped to world, un-normalised (planes: the unit edge direction)
-};
+// Declares the block's hit records and binds `best` to this lane's.
+#define BEST_IN_LDS(UV, best)                              \
+  __shared__ double hit_records[HIT_FIELDS(UV)][HIT_STRIDE]; \
+  best.rec = (LDS_AS double *)&hit_records[0][threadIdx.x];  \
+  best.prim = -1;                                          \
+  best.t = 0
 
 // ---- object <-> world maps --------------------------------------------------------------------
 // XfS: the static 3x4 pair stored in DPrim::xf.  The pointer is wave-uniform in the packet
@@ -188,9 +209,8 @@ DEV bool same(double a, double b) { return fabs(a - b) <= 2.220446049250313e-16;
 // the transformed bitangent with normal x tangent (e.g. Sphere.cpp:72-77), so it is never needed.
 template <class X> DEV void set_frame(Best<false> &, const X &, d3, d3, double, double) {}
 template <class X> DEV void set_frame(Best<true> &b, const X &xf, d3 ot, d3, double u, double v) {
-  b.tan = xf.world_dir(ot);
-  b.u = u;
-  b.v = v;
+  b.set_tan(xf.world_dir(ot));
+  b.set_uv(u, v);
 }
 
 // Common tail of the transformed intersectors: world point, world distance, raw normal.
@@ -202,8 +222,8 @@ DEV void commit(Best<UV> &b, const X &xf, const RayL &ray, d3 op, d3 on, int pri
   b.prim = prim;
   closest_t = t;
   if (!SHADOW) {
-    b.p = pw;
-    b.n = xf.world_normal(on);
+    b.set_p(pw);
+    b.set_n(xf.world_normal(on));
   }
 }
 
@@ -296,9 +316,8 @@ DEV void plane_frame(Best<false> &, ro_doubles, d3) {}
 DEV void plane_frame(Best<true> &b, ro_doubles pl, d3 ip) {
   const d3 e1 = ld3(pl + 12), e2 = ld3(pl + 16);
   const d3 local = ip - ld3(pl);
-  b.u = dot(local, e1) / pl[15];
-  b.v = dot(local, e2) / pl[19];
-  b.tan = e1;
+  b.set_uv(dot(local, e1) / pl[15], dot(local, e2) / pl[19]);
+  b.set_tan(e1);
 }
 template <bool SHADOW, bool UV>
 DEV void isect_plane(ro_doubles pl, int flags, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
@@ -317,8 +336,8 @@ DEV void isect_plane(ro_doubles pl, int flags, const RayL &ray, double t_min, do
   b.prim = prim;
   closest_t = t;
   if (!SHADOW) {
-    b.p = ip;
-    b.n = n;
+    b.set_p(ip);
+    b.set_n(n);
     if (UV) plane_frame(b, pl, ip);
   }
 }
@@ -329,6 +348,41 @@ DEV void isect_plane(ro_doubles pl, int flags, const RayL &ray, double t_min, do
 // double-precision Newton iteration on the implicit surface as in the reference (Torus.cpp:220-254),
 // which is what fixes the returned distance.
 #define TORUS_PEPS 1e-10
+// cos on [0, 1.1] and acos on [-1, 1] for the three-real-root case of the resolvent cubic: the
+// argument ranges are known, so neither needs the general routines' argument reduction (which
+// costs the kernels some 36 vector registers at their peak).  Both are accurate to about 1 ulp.
+DEV double cos_small(double x) {
+  const double z = x * x;
+  double p = 1.0 / 2432902008176640000.0;
+  p = p * z - 1.0 / 6402373705728000.0;
+  p = p * z + 1.0 / 20922789888000.0;
+  p = p * z - 1.0 / 87178291200.0;
+  p = p * z + 1.0 / 479001600.0;
+  p = p * z - 1.0 / 3628800.0;
+  p = p * z + 1.0 / 40320.0;
+  p = p * z - 1.0 / 720.0;
+  p = p * z + 1.0 / 24.0;
+  p = p * z - 0.5;
+  return p * z + 1.0;
+}
+DEV double acos_unit(double x) {
+  const double ax = fabs(x);
+  const bool small = ax < 0.5;
+  const double z = small ? x * x : (1.0 - ax) * 0.5;
+  const double pn = z * (1.66666666666666657415e-01 +
+                         z * (-3.25565818622400915405e-01 +
+                              z * (2.01212532134862925881e-01 +
+                                   z * (-4.00555345006794114027e-02 +
+                                        z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+  const double qn = 1.0 + z * (-2.40339491173441421878e+00 +
+                               z * (2.02094576023350569471e+00 +
+                                    z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+  const double r = pn / qn;
+  const double s = small ? x : sqrt(z);
+  const double v = s + s * r;  // asin(x) (small) or asin(sqrt(z))
+  if (small) return 1.57079632679489661923 - v;
+  return x < 0 ? 3.14159265358979323846 - 2.0 * v : 2.0 * v;
+}
 DEV int quad_roots(double b, double c, double *r) {  // x^2 + b x + c  (Torus.cpp:18-34)
   double disc = b * b - 4.0 * c;
   if (disc < -TORUS_PEPS) return 0;
@@ -358,7 +412,7 @@ DEV double cubic_first_root(double a, double b, double c) {  // x^3 + a x^2 + b 
   if (D == 0) return 2.0 * cbrt(-0.5 * q) - third * a;
   double arg = -0.5 * q / sqrt(-cube_p / 27.0);
   arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
-  return 2.0 * sqrt(-p / 3.0) * cos(acos(arg) * third) - third * a;
+  return 2.0 * sqrt(-p / 3.0) * cos_small(acos_unit(arg) * third) - third * a;
 }
 DEV int quartic_roots(const double *c, double *s) {  // c[0] + ... + c[4] x^4  (Torus.cpp:77-145)
   if (fabs(c[4]) < TORUS_PEPS) return 0;
@@ -450,8 +504,8 @@ DEV void isect_torus(const X &xf, ro_doubles prm, const RayL &ray, double t_min,
     const double rs = rho > 1e-10 ? rho : 1e-10;
     const double rad = (rho - R) / rs;
     const d3 on = unit(mk(hp.x * rad, hp.y * rad, hp.z));
-    b.p = pw;
-    b.n = xf.world_normal(on);
+    b.set_p(pw);
+    b.set_n(xf.world_normal(on));
     if (UV) {
       const double phi = atan2(hp.y, hp.x), theta = atan2(hp.z, rho - R);
       d3 ot = mk(-hp.y, hp.x, 0);
@@ -622,8 +676,8 @@ DEV void isect_cone(const X &xf, ro_doubles prm, const RayL &ray, double t_min, 
   b.prim = prim;
   closest_t = t;
   if (!SHADOW) {
-    b.p = pw;
-    b.n = xf.world_normal(on);
+    b.set_p(pw);
+    b.set_n(xf.world_normal(on));
     if (UV) {
       double u, v;
       d3 ot, ob;

@@ -30,12 +30,15 @@
 
 // Register budget of the two big kernels, as waves per SIMD the compiler must make room for.
 #ifndef MIRT_TRACE_WAVES
-#define MIRT_TRACE_WAVES 2
+#define MIRT_TRACE_WAVES 3
 #endif
 #ifndef MIRT_SHADOW_WAVES
-#define MIRT_SHADOW_WAVES 2
+#define MIRT_SHADOW_WAVES 3
 #endif
 #define WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+// Keeps the compiler from carrying values in registers across a section whose register budget is
+// tight: what is stored to LDS before the fence has to be loaded again after the next one.
+#define PARK_FENCE() asm volatile("" ::: "memory")
 
 // Development aid: -DMIRT_PROFILE=1 (trace kernel) or =2 (shadow kernel) replaces the statistics
 // counters by shader-clock cycles per wave spent in the kernel's sections.
@@ -138,12 +141,12 @@ template <> struct Surface<true> {
 
 DEV void finish_frame(Surface<false> &, const Best<false> &, bool) {}
 DEV void finish_frame(Surface<true> &s, const Best<true> &b, bool plane) {
-  s.u = b.u;
-  s.v = b.v;
+  s.u = b.u();
+  s.v = b.v();
   if (plane) {
-    s.tan = b.tan;  // Plane.cpp:124
+    s.tan = b.tan();  // Plane.cpp:124
   } else {
-    d3 t = unit(unit(b.tan));  // Transform.cpp:112-114 then e.g. Sphere.cpp:72
+    d3 t = unit(unit(b.tan()));  // Transform.cpp:112-114 then e.g. Sphere.cpp:72
     s.tan = unit(t - s.n * dot(t, s.n));
   }
   s.bit = unit(cross(s.n, s.tan));
@@ -153,10 +156,11 @@ DEV void finish_frame(Surface<true> &s, const Best<true> &b, bool plane) {
 template <bool UV> DEV Surface<UV> make_surface(const DScene &sc, const RayL &ray, const Best<UV> &b) {
   Surface<UV> s;
   const bool plane = sc.prims[b.prim].type == MIRT_PLANE;
-  const d3 n = plane ? b.n : unit(unit(b.n));
+  const d3 bn = b.n();
+  const d3 n = plane ? bn : unit(unit(bn));
   s.front = dot(ray.d, n) < 0;
   s.n = s.front ? n : -n;
-  s.p = b.p;
+  s.p = b.p();
   finish_frame(s, b, plane);
   return s;
 }
@@ -413,15 +417,26 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 
   const RayL ray = make_ray(ro, rd, time);
   Best<UV> best;
-  best.prim = -1;
-  best.t = 0;
-  best.p = mk(0, 0, 0);
-  best.n = mk(0, 0, 1);
+  BEST_IN_LDS(UV, best);
   double closest = 1.7976931348623157e308;  // numeric_limits<double>::max() (Raytracer.cpp:300)
 #if MIRT_PROFILE == 1
   PROF_MARK(0);
 #endif
+  // the ray's weight, key and pixel wait in LDS while the traversal needs the registers
+  __shared__ double park_w[3][256];
+  __shared__ uint64_t park_key[256];
+  __shared__ uint32_t park_pixel[256];
+  park_w[0][threadIdx.x] = W.x;
+  park_w[1][threadIdx.x] = W.y;
+  park_w[2][threadIdx.x] = W.z;
+  park_key[threadIdx.x] = key;
+  park_pixel[threadIdx.x] = pixel;
+  PARK_FENCE();
   traverse_packet<false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
+  PARK_FENCE();
+  W = mk(park_w[0][threadIdx.x], park_w[1][threadIdx.x], park_w[2][threadIdx.x]);
+  key = park_key[threadIdx.x];
+  pixel = park_pixel[threadIdx.x];
 #if MIRT_PROFILE == 1
   PROF_MARK(1);
 #endif
@@ -610,18 +625,42 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_TRACE_WAVES) void k_trace(
 // is a small state machine -- stratum index, distance walked, attenuation -- and the wave runs
 // closest-hit segments until every lane is done, so lanes with many strata or glass on the way do
 // not hold the others idle between their segments.  Shadow rays are at shutter time 0.5 (Ray.h:15).
+//
+// While a segment is being traced, the lane's walk state that the traversal does not touch is
+// parked in LDS and the parts of the work item that are only needed later (colour, pixel, random
+// key, light) stay in memory: the traversal with its inlined intersectors sets the kernel's vector
+// register peak, and every register freed there counts towards one more resident wave per SIMD.
 DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_node, unsigned &n_prim,
                       unsigned &n_seg) {
+  // per lane: the item (point, colour, key, pixel, light), the light's strata, and the walk state
+  __shared__ double park_p[3][256], park_c[3][256], park_w[4][256], park_inv_n[256];  // park_w: total att cur dist
+  __shared__ uint64_t park_key[256];
+  __shared__ uint32_t park_pixel[256], park_light[256], park_dim[256];
+  __shared__ int32_t park_side[256];
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
+  const int tid = threadIdx.x;
 #if MIRT_PROFILE == 2
   PROF_DECL;
 #endif
-  const DShadowItem it = a.items[slot];
-  const d3 P = ld3(it.p);
-  const mirt_light &L = sc.lights[it.light];
-  const DLightFrame lf = a.fr.light_frame[it.light];
-  const int side = lf.side, n = side * side;
+  d3 P;
+  {
+    const DShadowItem it = a.items[slot];
+    const DLightFrame lf = a.fr.light_frame[it.light];
+    P = ld3(it.p);
+    park_p[0][tid] = it.p[0];
+    park_p[1][tid] = it.p[1];
+    park_p[2][tid] = it.p[2];
+    park_c[0][tid] = it.c[0];
+    park_c[1][tid] = it.c[1];
+    park_c[2][tid] = it.c[2];
+    park_key[tid] = it.key;
+    park_pixel[tid] = it.pixel;
+    park_light[tid] = it.light;
+    park_dim[tid] = lf.dim;
+    park_side[tid] = lf.side;
+    park_inv_n[tid] = lf.inv_n;
+  }
   double eps = cfg.ray_offset_epsilon;
   if (cfg.use_adaptive_epsilon) eps += len(P) * cfg.adaptive_epsilon_scale;
 
@@ -631,11 +670,16 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
   bool busy = false;
   // moves to the next stratum that has a segment to walk; returns false when all strata are done
   auto next_stratum = [&]() {
+    const int side = park_side[tid], n = side * side;
+    if (s >= n) return false;
+    const mirt_light &L = sc.lights[park_light[tid]];
+    const uint64_t key = park_key[tid];
+    const uint32_t dim0 = park_dim[tid];
     while (s < n) {
       const int si = s / side, sj = s % side;
-      const uint32_t dim = lf.dim + 2u * (uint32_t)s;
-      const double u = (si + mirt_rng_draw(it.key, dim)) / side;
-      const double v = (sj + mirt_rng_draw(it.key, dim + 1)) / side;
+      const uint32_t dim = dim0 + 2u * (uint32_t)s;
+      const double u = (si + mirt_rng_draw(key, dim)) / side;
+      const double v = (sj + mirt_rng_draw(key, dim + 1)) / side;
       const d3 to = light_point(L, u, v) - P;
       dist = len(to);
       dir = to / dist;
@@ -654,10 +698,16 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
   while (__any(busy)) {
     const RayL ray = make_ray(P + dir * cur, dir, 0.5);
     double closest = dist - cur;
-    Best<false> best;
+    Best<false> best;  // shadow segments record no hit point
+    best.rec = nullptr;
     best.prim = -1;
     best.t = 0;
     if (busy) n_seg++;
+    park_w[0][tid] = total;
+    park_w[1][tid] = att;
+    park_w[2][tid] = cur;
+    park_w[3][tid] = dist;
+    PARK_FENCE();
 #if MIRT_PROFILE == 2
     PROF_MARK(2);
 #endif
@@ -665,6 +715,13 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
 #if MIRT_PROFILE == 2
     PROF_MARK(1);
 #endif
+    PARK_FENCE();
+    P = mk(park_p[0][tid], park_p[1][tid], park_p[2][tid]);
+    total = park_w[0][tid];
+    att = park_w[1][tid];
+    cur = park_w[2][tid];
+    dist = park_w[3][tid];
+    dir = ray.d;
     if (busy) {
       bool done = true;
       if (best.prim >= 0 && best.t < (dist - cur)) {
@@ -686,8 +743,9 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
     }
   }
   if (valid) {
-    const double shadow = total * lf.inv_n;
-    if (!(shadow >= 1.0)) pixel_add(a.accum, it.pixel, ld3(it.c) * (1.0 - shadow));  // Raytracer.cpp:264,271
+    const double shadow = total * park_inv_n[tid];
+    if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
+      pixel_add(a.accum, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
   }
 #if MIRT_PROFILE == 2
   PROF_MARK(3);
@@ -745,12 +803,7 @@ __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
   camera_ray(a.cam, gx + 0.5, gy + 0.5, a.width, a.height, 0, ro, rd);
   const RayL ray = make_ray(ro, rd, 0.5);
   Best<true> best;
-  best.prim = -1;
-  best.t = 0;
-  best.p = mk(0, 0, 0);
-  best.n = mk(0, 0, 1);
-  best.u = best.v = 0;
-  best.tan = mk(1, 0, 0);
+  BEST_IN_LDS(true, best);
   double closest = 1.7976931348623157e308;
   unsigned nn = 0, np = 0;
   traverse_packet<false, true, false>(a.sc, ray, active, 1e-5, closest, best, nn, np);
@@ -779,10 +832,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(const RaysArgs a) {
   const size_t j = active ? i : 0;
   const RayL ray = make_ray(ld3(a.origin + 3 * j), ld3(a.dir + 3 * j), a.time ? a.time[j] : 0.5);
   Best<false> best;
-  best.prim = -1;
-  best.t = 0;
-  best.p = mk(0, 0, 0);
-  best.n = mk(0, 0, 1);
+  BEST_IN_LDS(false, best);
   double closest = a.t_max ? a.t_max[j] : 1.7976931348623157e308;
   unsigned nn = 0, np = 0;
   traverse_packet<false, false, true>(a.sc, ray, active, a.t_min, closest, best, nn, np);
