@@ -109,6 +109,10 @@ def main():
     over = dict(max_ray_depth=args.max_depth, glossy_samples=args.glossy_reflection)
     if args.soft_shadows is not None:
         over["shadow_samples"] = args.soft_shadows
+    # per-kernel HIP events (for the roofline entry) cost ~10 us per launch: kept on at N = 1, where the
+    # frame is long; at N > 1 the timed region runs without them and one extra frame after it is timed
+    # per kernel
+    over["kernel_timing"] = 1 if world == 1 else 0
     cfg = default_config(**over)
     W, H, spp, tile = args.width, args.height, args.spp, D.TILE
 
@@ -142,6 +146,12 @@ def main():
         acc = st if acc is None else {k: acc[k] + st[k] for k in st}
     barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        cfg.kernel_timing = 1
+        _, st = step()
+        for k in ("trace_kernel_ms", "shadow_kernel_ms", "trace_kernel_launches", "shadow_kernel_launches"):
+            acc[k] = st[k] * args.steps
+        barrier()
 
     keys = ["primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
             "shadow_prim_tests", "trace_kernel_launches", "shadow_kernel_launches"]

@@ -172,7 +172,8 @@ typedef struct mirt_config {
   double gamma;
   uint64_t seed;      /* seed of the addressed random function (mirt_rng.h) */
   int32_t sampling;   /* MIRT_SAMPLING_* */
-  int32_t pad_;
+  int32_t kernel_timing; /* nonzero: bracket every kernel launch with events and fill the *_kernel_ms
+                            statistics (costs a few microseconds per launch); zero: device_ms only */
 } mirt_config;
 
 /* Counters and timings of one mirt_render* call. */

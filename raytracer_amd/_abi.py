@@ -72,7 +72,7 @@ class Config(C.Structure):
                 ("ambient_factor", C.c_double), ("ray_offset_epsilon", C.c_double),
                 ("adaptive_epsilon_scale", C.c_double), ("pure_glass_threshold", C.c_double),
                 ("exposure", C.c_double), ("gamma", C.c_double), ("seed", C.c_uint64),
-                ("sampling", C.c_int32), ("pad_", C.c_int32)]
+                ("sampling", C.c_int32), ("kernel_timing", C.c_int32)]
 
 
 class Stats(C.Structure):

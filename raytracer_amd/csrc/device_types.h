@@ -182,7 +182,7 @@ struct ShadowArgs {
 };
 
 struct ResolveArgs {
-  const double *accum;
+  double *accum;  // read, then zeroed for the next frame
   double *out;
   uint32_t n_pixels;
   int32_t spp;

@@ -107,11 +107,15 @@ struct mirt_scene {
   SpawnKinds kinds;
   // per-frame working memory, grown on demand and kept
   RayQueueMem queues[2];  // rays of even / odd depth: a depth reads one and appends to the other
-  DeviceBuffer shadow_items, control, counters, accum, out, ids;
+  DeviceBuffer shadow_items, control, accum, out, ids;  // control: statistics counters, then the queue tails
   char *pinned = nullptr;  // read-back of the tail counters and the statistics
   size_t pinned_bytes = 0;
   size_t ray_shard_cap = 0, shadow_shard_cap = 0;  // entries per queue shard
   uint64_t split_for = 0;  // frame shape (primary grid blocks, depth, glossy samples) `split` was found for
+  int light_frame_for = 0;  // shadow_samples the device copy of the lights' strata was made for
+  bool light_frame_valid = false;
+  bool accum_clean = false;  // the accumulation buffer is all zero (k_resolve leaves it so)
+  size_t accum_clean_bytes = 0;
   uint32_t split = 1;      // primary launches are cut this many times finer than the queues' sizes suggest
   std::vector<hipEvent_t> events;
   ~mirt_scene() {
@@ -421,6 +425,7 @@ MIRT_API void mirt_config_defaults(mirt_config *c) {
   c->gamma = 2.2;
   c->seed = 0;
   c->sampling = MIRT_SAMPLING_JITTER;
+  c->kernel_timing = 0;
 }
 
 MIRT_API void mirt_scene_destroy(mirt_scene *scene) {
@@ -513,7 +518,6 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   HIP_TRY(upload(sc->lights, sc->host_lights));
   HIP_TRY(upload(sc->textures, textures));
   HIP_TRY(sc->light_frame.reserve(std::max<size_t>(sizeof(DLightFrame) * s.n_lights, 16)));
-  HIP_TRY(sc->counters.reserve(COUNTER_SHARDS * sizeof(DCounters)));
 
   DScene &d = sc->d;
   d.nodes = sc->nodes.as<DNode>();
@@ -594,7 +598,13 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     lf[l].inv_n = 1.0 / (side * side);
     dim += 2u * (uint32_t)(side * side);
   }
-  if (n_lights) HIP_TRY(hipMemcpyAsync(sc->light_frame.p, lf.data(), sizeof(DLightFrame) * n_lights, hipMemcpyHostToDevice, stream));
+  if (n_lights && (sc->light_frame_for != config->shadow_samples || !sc->light_frame_valid)) {
+    // blocking copy from pageable memory: done once per shadow_samples value, not per frame
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(sc->light_frame.p, lf.data(), sizeof(DLightFrame) * n_lights, hipMemcpyHostToDevice));
+    sc->light_frame_for = config->shadow_samples;
+    sc->light_frame_valid = true;
+  }
   fr.light_frame = sc->light_frame.as<DLightFrame>();
 
   // ---- working memory ------------------------------------------------------------------------
@@ -619,7 +629,11 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   if (want_r > sc->ray_shard_cap) sc->ray_shard_cap = want_r;
   if (want_s > sc->shadow_shard_cap) sc->shadow_shard_cap = want_s;
   HIP_TRY(sc->shadow_items.reserve(sc->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem)));
-  HIP_TRY(sc->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
+  {
+    const void *before = sc->accum.p;
+    HIP_TRY(sc->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
+    if (sc->accum.p != before) sc->accum_clean = false;
+  }
   if (levels > 1) {
     HIP_TRY(ensure_queue(sc, 0));
     HIP_TRY(ensure_queue(sc, 1));
@@ -634,7 +648,6 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     sc->split_for = shape;
     sc->split = 1;
   }
-  DCounters *counters = sc->counters.as<DCounters>();
   const bool uv = sc->d.any_maps && config->enable_textures;
   const bool motion = sc->d.any_motion && config->enable_motion_blur && config->sampling == MIRT_SAMPLING_JITTER;
 
@@ -651,13 +664,16 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     const uint64_t per_launch = std::max<uint64_t>(1, fit / (uint64_t)spp / sc->split);
     const size_t chunks = total_blocks ? (size_t)((total_blocks + per_launch - 1) / per_launch) : 0;
     // tail counters: per primary launch and level, the rays and the shadow items that level queued
-    const size_t control_bytes = std::max<size_t>(chunks * (size_t)std::max(levels, 0) * 2 * kCountBytes, 64);
+    const size_t stats_bytes = COUNTER_SHARDS * sizeof(DCounters);
+    const size_t control_bytes = stats_bytes + chunks * (size_t)std::max(levels, 0) * 2 * kCountBytes;
     HIP_TRY(sc->control.reserve(control_bytes));
-    HIP_TRY(ensure_pinned(sc, control_bytes + COUNTER_SHARDS * sizeof(DCounters)));
+    HIP_TRY(ensure_pinned(sc, control_bytes));
+    DCounters *counters = sc->control.as<DCounters>();
     auto tails = [&](size_t chunk, int level, int what) {  // what: 0 rays, 1 shadow items
-      return reinterpret_cast<uint32_t *>(sc->control.as<char>() +
+      return reinterpret_cast<uint32_t *>(sc->control.as<char>() + stats_bytes +
                                           ((chunk * (size_t)levels + (size_t)level) * 2 + (size_t)what) * kCountBytes);
     };
+    const bool kernel_timing = config->kernel_timing != 0;
 
     ev_used = 0;
     timed.clear();
@@ -665,9 +681,10 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     HIP_TRY(get_event(sc, ev_used, ev_begin));
     HIP_TRY(get_event(sc, ev_used, ev_end));
     HIP_TRY(hipEventRecord(ev_begin, stream));
-    HIP_TRY(hipMemsetAsync(counters, 0, COUNTER_SHARDS * sizeof(DCounters), stream));
     HIP_TRY(hipMemsetAsync(sc->control.p, 0, control_bytes, stream));
-    if (n_pixels) HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
+    if (n_pixels && !(sc->accum_clean && sc->accum_clean_bytes >= n_pixels * 3 * sizeof(double)))
+      HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
+    sc->accum_clean = false;
 
     for (size_t c = 0; c < chunks && levels > 0; ++c) {
       const uint64_t b0 = c * per_launch;
@@ -695,9 +712,11 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
         a.n = nb;
         a.depth = depth;
         Timed t{nullptr, nullptr, 0};
-        HIP_TRY(get_event(sc, ev_used, t.a));
-        HIP_TRY(get_event(sc, ev_used, t.b));
-        HIP_TRY(hipEventRecord(t.a, stream));
+        if (kernel_timing) {
+          HIP_TRY(get_event(sc, ev_used, t.a));
+          HIP_TRY(get_event(sc, ev_used, t.b));
+          HIP_TRY(hipEventRecord(t.a, stream));
+        }
         const unsigned grid = depth == 0 ? nb * (unsigned)spp : consumer_grid;
         launch_trace(depth == 0, uv, motion, grid, stream, a);
         {
@@ -705,8 +724,10 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
           if (le != hipSuccess)
             return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u): %s", depth, grid, hipGetErrorString(le));
         }
-        HIP_TRY(hipEventRecord(t.b, stream));
-        timed.push_back(t);
+        if (kernel_timing) {
+          HIP_TRY(hipEventRecord(t.b, stream));
+          timed.push_back(t);
+        }
 
         ShadowArgs sa;
         std::memset(&sa, 0, sizeof sa);
@@ -718,13 +739,17 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
         sa.accum = sc->accum.as<double>();
         sa.counters = counters;
         Timed ts{nullptr, nullptr, 1};
-        HIP_TRY(get_event(sc, ev_used, ts.a));
-        HIP_TRY(get_event(sc, ev_used, ts.b));
-        HIP_TRY(hipEventRecord(ts.a, stream));
+        if (kernel_timing) {
+          HIP_TRY(get_event(sc, ev_used, ts.a));
+          HIP_TRY(get_event(sc, ev_used, ts.b));
+          HIP_TRY(hipEventRecord(ts.a, stream));
+        }
         launch_shadow(consumer_grid, stream, sa);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ts.b, stream));
-        timed.push_back(ts);
+        if (kernel_timing) {
+          HIP_TRY(hipEventRecord(ts.b, stream));
+          timed.push_back(ts);
+        }
         launches += 2;
       }
     }
@@ -740,18 +765,18 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
       launch_resolve((unsigned)((n_pixels + 255) / 256), stream, r);
       HIP_TRY(hipGetLastError());
       launches++;
+      sc->accum_clean = true;  // k_resolve zeroes what it reads
+      sc->accum_clean_bytes = n_pixels * 3 * sizeof(double);
     }
     HIP_TRY(hipEventRecord(ev_end, stream));
     HIP_TRY(hipMemcpyAsync(sc->pinned, sc->control.p, control_bytes, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(sc->pinned + control_bytes, counters, COUNTER_SHARDS * sizeof(DCounters),
-                           hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    host_counters = reinterpret_cast<const DCounters *>(sc->pinned + control_bytes);
+    host_counters = reinterpret_cast<const DCounters *>(sc->pinned);
 
     // did every queue shard hold what was appended to it?
     bool overflow = false;
     secondary = 0;
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(sc->pinned);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(sc->pinned + stats_bytes);
     for (size_t c = 0; c < chunks; ++c)
       for (int level = 0; level < levels; ++level)
         for (int s = 0; s < QUEUE_SHARDS; ++s) {

@@ -770,7 +770,8 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_SHADOW_WAVES) void k_shado
 }
 
 
-// Raytracer.cpp:544-568: mean, optional tone map, gamma on un-clamped values.
+// Raytracer.cpp:544-568: mean, optional tone map, gamma on un-clamped values.  Leaves the
+// accumulation buffer zeroed, which spares the next frame a fill launch.
 __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= a.n_pixels) return;
@@ -778,6 +779,7 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     double x = a.accum[3 * (size_t)i + k] / a.spp;
+    a.accum[3 * (size_t)i + k] = 0.0;
     if (a.cfg.tone_mapping_mode == MIRT_TONEMAP_REINHARD) {
       x = x / (1.0 + x);
     } else if (a.cfg.tone_mapping_mode == MIRT_TONEMAP_EXPOSURE) {
