@@ -16,7 +16,7 @@ HOST := raytracer_amd/host
 ENGINE_SRCS := $(wildcard $(CSRC)/*.hip)
 ENGINE_HDRS := $(wildcard $(CSRC)/*.h) include/mirt.h include/mirt_rng.h
 HOST_SRCS := $(HOST)/mirt_math.cpp $(HOST)/scene_loader.cpp $(HOST)/image_io.cpp $(HOST)/flatten.cpp \
-             $(HOST)/render.cpp $(HOST)/capi.cpp
+             $(HOST)/render.cpp $(HOST)/capi.cpp $(HOST)/synthetic.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.h) include/mirt.h
 
 HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function \

@@ -244,6 +244,12 @@ int mirt_trace_rays(mirt_scene *scene, int64_t n, const double *origin, const do
                     const double *time, double t_min, const double *t_max, int32_t *prim_id, double *t,
                     double *normal);
 
+/* Engine tuning, no counterpart in the reference: how rays walk the BVH.  Both walks test the same
+ * boxes and primitives in the same order per ray (Bvh.cpp:306-333) and return the same hits.
+ * MIRT_TRAVERSAL_AUTO picks by scene size (packet for scenes of a few dozen primitives). */
+enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE = 2 };
+int mirt_scene_set_traversal(mirt_scene *scene, int mode);
+
 const char *mirt_last_error(void);
 int mirt_abi_version(void);
 

@@ -19,6 +19,7 @@ FIX = os.path.join(ROOT, "fixtures")
 OUT = os.path.join(ROOT, "tests", "golden")
 SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene"]
 W, H = 96, 54  # deterministic (pixel-centre) maps
+SYNTHETIC = [("synthetic100k", 100000, 0x5EED)]  # generated scenes (raytracer_amd/host/synthetic.h): a deep BVH
 
 # stochastic renders: (name, scene, w, h, spp, harness flags); tests/golden_cases.py maps the flags
 # to mirt_config fields
@@ -35,8 +36,8 @@ RENDERS = [
 ]
 
 
-def harness(*args):
-    r = subprocess.run([HARNESS, "--root", FIX, *args], check=True, capture_output=True)
+def harness(*args, root=FIX):
+    r = subprocess.run([HARNESS, "--root", root, *args], check=True, capture_output=True)
     return r.stdout, r.stderr.decode()
 
 
@@ -47,17 +48,25 @@ def main():
     n = W * H
     dumps = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for s in SCENES:
+        # the generated scenes reach the reference through its own parser, as ASCII files
+        sys.path.insert(0, ROOT)
+        from raytracer_amd import HostScene
+        os.makedirs(os.path.join(tmp, "ASCII"))
+        for name, count, seed in SYNTHETIC:
+            HostScene.synthetic(count, seed).write_ascii(os.path.join(tmp, "ASCII", f"{name}.txt"))
+        for s in SCENES + [name for name, _, _ in SYNTHETIC]:
             scene = f"ASCII/{s}.txt"
-            dumps[f"{s}_scene"] = np.frombuffer(harness("dump-scene", scene)[0], dtype=np.uint8)
-            dumps[f"{s}_bvh"] = np.frombuffer(harness("dump-bvh", scene)[0], dtype=np.uint8)
+            root = FIX if s in SCENES else tmp
+            if s in SCENES:
+                dumps[f"{s}_scene"] = np.frombuffer(harness("dump-scene", scene)[0], dtype=np.uint8)
+                dumps[f"{s}_bvh"] = np.frombuffer(harness("dump-bvh", scene)[0], dtype=np.uint8)
             out = os.path.join(tmp, "h.bin")
-            harness("hits", scene, str(W), str(H), out)
+            harness("hits", scene, str(W), str(H), out, root=root)
             raw = np.fromfile(out, dtype=np.uint8)
             ids = raw[: 4 * n].view(np.int32)
             front = raw[4 * n: 8 * n].view(np.int32)
             rest = raw[8 * n:].view(np.float64)
-            harness("trace", scene, str(W), str(H), out, "--max-depth", "5", "--motion-blur", "0")
+            harness("trace", scene, str(W), str(H), out, "--max-depth", "5", "--motion-blur", "0", root=root)
             rgb = np.fromfile(out, dtype=np.float64)
             np.savez_compressed(
                 os.path.join(OUT, f"hits_{s}.npz"), width=W, height=H, prim_id=ids, front=front, t=rest[:n],

@@ -88,7 +88,8 @@ class Stats(C.Structure):
 
 ENGINE_SYMBOLS = [
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
-    "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_last_error", "mirt_abi_version",
+    "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal",
+    "mirt_last_error", "mirt_abi_version",
 ]
 
 
@@ -108,12 +109,17 @@ def _declare_engine(lib):
     lib.mirt_tile_buffer_pixels.restype = C.c_int64
     lib.mirt_trace_ids.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, dp]
     lib.mirt_trace_rays.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp, C.c_double, dp, C.POINTER(C.c_int32), dp, dp]
+    lib.mirt_scene_set_traversal.argtypes = [C.c_void_p, C.c_int]
     lib.mirt_last_error.restype = C.c_char_p
     lib.mirt_abi_version.restype = C.c_int
     return lib
 
 
 def _declare_host(lib):
+    lib.mirt_host_scene_synthetic.restype = C.c_void_p
+    lib.mirt_host_scene_synthetic.argtypes = [C.c_int, C.c_uint64]
+    lib.mirt_host_scene_write_ascii.restype = C.c_int
+    lib.mirt_host_scene_write_ascii.argtypes = [C.c_void_p, C.c_char_p]
     lib.mirt_host_scene_load.restype = C.c_void_p
     lib.mirt_host_scene_load.argtypes = [C.c_char_p, C.c_char_p]
     lib.mirt_host_scene_free.argtypes = [C.c_void_p]

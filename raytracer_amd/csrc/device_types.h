@@ -207,10 +207,11 @@ struct RaysArgs {
 };
 
 // Launchers defined in kernels.hip (the only translation unit compiled for the GPU).
+// packet: wave-coherent BVH walk (one node index per wave) instead of the per-lane walk;
 // uv: the scene samples image maps, so hits carry texture coordinates and a tangent frame;
 // motion: some ray of the launch may be at a shutter time other than 0.5.
-void launch_trace(bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
-void launch_shadow(unsigned grid, void *stream, const ShadowArgs &a);
+void launch_trace(bool packet, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
+void launch_shadow(bool packet, unsigned grid, void *stream, const ShadowArgs &a);
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a);
-void launch_trace_ids(unsigned grid, void *stream, const IdsArgs &a);
-void launch_trace_rays(unsigned grid, void *stream, const RaysArgs &a);
+void launch_trace_ids(bool packet, unsigned grid, void *stream, const IdsArgs &a);
+void launch_trace_rays(bool packet, unsigned grid, void *stream, const RaysArgs &a);

@@ -99,6 +99,8 @@ struct SpawnKinds {
 
 struct mirt_scene {
   int device = 0;
+  bool packet = true;  // BVH walk: wave-coherent (small scenes) or per lane
+  int n_prims = 0;
   hipStream_t stream = nullptr;
   DScene d{};
   DeviceBuffer nodes, leaf_prims, prims, motion, materials, transparency, lights, textures, light_frame;
@@ -434,6 +436,23 @@ MIRT_API void mirt_scene_destroy(mirt_scene *scene) {
   delete scene;
 }
 
+MIRT_API int mirt_scene_set_traversal(mirt_scene *scene, int mode) {
+  if (!scene) return fail(MIRT_ERR_INVALID, "NULL scene");
+  if (mode == MIRT_TRAVERSAL_AUTO) {
+    // the packet walk visits the union of its 64 rays' paths: best while the tree is a handful of
+    // nodes (MIRT_TRAVERSAL=packet|lane overrides the choice for experiments)
+    const char *env = std::getenv("MIRT_TRAVERSAL");
+    scene->packet = (size_t)scene->n_prims <= env_size("MIRT_PACKET_MAX_PRIMS", 64);
+    if (env && std::strcmp(env, "packet") == 0) scene->packet = true;
+    if (env && std::strcmp(env, "lane") == 0) scene->packet = false;
+  } else if (mode == MIRT_TRAVERSAL_PACKET || mode == MIRT_TRAVERSAL_LANE) {
+    scene->packet = mode == MIRT_TRAVERSAL_PACKET;
+  } else {
+    return fail(MIRT_ERR_INVALID, "unknown traversal mode %d", mode);
+  }
+  return MIRT_OK;
+}
+
 MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
   if (!out) return fail(MIRT_ERR_INVALID, "out is NULL");
   *out = nullptr;
@@ -491,6 +510,8 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   for (const auto &m : materials)
     if ((m.has_texture && m.texture >= 0) || m.normal_map >= 0 || m.bump_map >= 0) any_maps = true;
   sc->kinds = spawn_kinds(s);
+  sc->n_prims = s.n_prims;
+  mirt_scene_set_traversal(sc, MIRT_TRAVERSAL_AUTO);
 
   std::vector<DTexture> textures(s.n_textures);
   sc->texels.resize(s.n_textures);
@@ -718,7 +739,7 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
           HIP_TRY(hipEventRecord(t.a, stream));
         }
         const unsigned grid = depth == 0 ? nb * (unsigned)spp : consumer_grid;
-        launch_trace(depth == 0, uv, motion, grid, stream, a);
+        launch_trace(sc->packet, depth == 0, uv, motion, grid, stream, a);
         {
           const hipError_t le = hipGetLastError();
           if (le != hipSuccess)
@@ -744,7 +765,7 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
           HIP_TRY(get_event(sc, ev_used, ts.b));
           HIP_TRY(hipEventRecord(ts.a, stream));
         }
-        launch_shadow(consumer_grid, stream, sa);
+        launch_shadow(sc->packet, consumer_grid, stream, sa);
         HIP_TRY(hipGetLastError());
         if (kernel_timing) {
           HIP_TRY(hipEventRecord(ts.b, stream));
@@ -891,7 +912,7 @@ MIRT_API int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int wi
   a.normal = reinterpret_cast<double *>(base + off_n);
   a.uv = reinterpret_cast<double *>(base + off_uv);
   const unsigned grid = (unsigned)(((width + 15) / 16) * ((height + 15) / 16));
-  launch_trace_ids(grid, scene->stream, a);
+  launch_trace_ids(scene->packet, grid, scene->stream, a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(scene->stream));
   HIP_TRY(hipMemcpy(prim_id, a.prim_id, n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -928,7 +949,7 @@ MIRT_API int mirt_trace_rays(mirt_scene *scene, int64_t n, const double *origin,
   a.t_max = t_max ? d_tmax : nullptr;
   a.t_min = t_min;
   a.n = (uint32_t)N;
-  launch_trace_rays((unsigned)((N + 255) / 256), scene->stream, a);
+  launch_trace_rays(scene->packet, (unsigned)((N + 255) / 256), scene->stream, a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(scene->stream));
   HIP_TRY(hipMemcpy(prim_id, a.prim_id, N * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -383,6 +383,41 @@ DEV double acos_unit(double x) {
   if (small) return 1.57079632679489661923 - v;
   return x < 0 ? 3.14159265358979323846 - 2.0 * v : 2.0 * v;
 }
+// Double-double helpers (value = hi + lo, |lo| <= ulp(hi)/2) for the Taylor shift below.
+struct dd {
+  double hi, lo;
+};
+DEV dd dd_add_d(dd a, double b) {  // a + b
+  const double s = a.hi + b, bb = s - a.hi;
+  const double e = ((a.hi - (s - bb)) + (b - bb)) + a.lo;
+  const double hi = s + e;
+  return dd{hi, e - (hi - s)};
+}
+DEV dd dd_add(dd a, dd b) {
+  const double s = a.hi + b.hi, bb = s - a.hi;
+  const double e = ((a.hi - (s - bb)) + (b.hi - bb)) + (a.lo + b.lo);
+  const double hi = s + e;
+  return dd{hi, e - (hi - s)};
+}
+DEV dd dd_mul_d(dd a, double b) {  // a * b, the product of the leading parts exact through one fused multiply-add
+  const double p = a.hi * b;
+  const double e = __builtin_fma(a.hi, b, -p) + a.lo * b;
+  const double hi = p + e;
+  return dd{hi, e - (hi - p)};
+}
+// c[0..4] := coefficients of p(x + h), by repeated synthetic division in double-double.
+DEV void taylor_shift_quartic(double *c, double h) {
+  dd a[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) a[i] = dd{c[i], 0.0};
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+#pragma unroll
+    for (int i = 3; i >= pass; i--) a[i] = dd_add(dd_mul_d(a[i + 1], h), a[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) c[i] = a[i].hi + a[i].lo;
+}
 DEV int quad_roots(double b, double c, double *r) {  // x^2 + b x + c  (Torus.cpp:18-34)
   double disc = b * b - 4.0 * c;
   if (disc < -TORUS_PEPS) return 0;
@@ -460,6 +495,8 @@ DEV void isect_torus(const X &xf, ro_doubles prm, const RayL &ray, double t_min,
   const double cs = oo - tot * tot;
   if (cs > 0 && od > 0) return;
   if (od * od - cs < 0) return;
+  // The quartic's coefficients in the ray parameter measured from the ray origin, computed in double
+  // exactly as the reference computes them (Torus.cpp:186-199).
   const double beta = 2 * od, gamma = oo - r2 - R2;
   double c[5], roots[4];
   c[4] = 1.0;
@@ -467,16 +504,28 @@ DEV void isect_torus(const X &xf, ro_doubles prm, const RayL &ray, double t_min,
   c[2] = beta * beta + 2 * gamma + fR2 * d.z * d.z;
   c[1] = 2 * beta * gamma + 2 * fR2 * o.z * d.z;
   c[0] = gamma * gamma + fR2 * (o.z * o.z - r2);
+  // The reference then finds the roots in x87 long double.  Seen from far away they sit in a tight
+  // cluster hundreds of torus sizes out, which Ferrari's method in plain double cannot resolve; for
+  // such rays the polynomial is first re-centred on the point of the ray nearest the torus centre,
+  // with the Taylor shift carried out in double-double (exact to ~1e-32), and the re-centred, now
+  // well-conditioned quartic is solved in double.  The roots are those of the reference's own
+  // polynomial, rounding of its coefficients included.  Closer than a hundred torus sizes plain
+  // double resolves the roots to better than 1e-7 of the torus size and the polynomial is solved as it is.
+  const bool far = oo > 1.0e4 * (tot * tot);
+  const double shift = far ? -od : 0.0;
+  if (far) taylor_shift_quartic(c, shift);
   const int nr = quartic_roots(c, roots);
   const double lo = t_min * dl, hi = closest_t * dl;
   double cur = hi;
   bool any = false;
 #pragma unroll
-  for (int i = 0; i < 4; i++)
-    if (i < nr && roots[i] >= lo && roots[i] < cur) {
-      cur = roots[i];
+  for (int i = 0; i < 4; i++) {
+    const double root = roots[i] + shift;
+    if (i < nr && root >= lo && root < cur) {
+      cur = root;
       any = true;
     }
+  }
   if (!any) return;
   double tr = cur;
   for (int i = 0; i < 3; i++) {

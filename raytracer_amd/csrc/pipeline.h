@@ -126,6 +126,52 @@ DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double 
   }
 }
 
+// The same walk with one node index per LANE, for scenes whose rays do not share their path through
+// the tree: each lane follows its own skip links until it stands on a leaf whose box it hits (or
+// runs out of nodes), then all lanes intersect their leaf's primitives together.  Node and primitive
+// records are fetched per lane; the branches on primitive and transform kind diverge, so a wave
+// pays for every kind some lane holds.  The sequence of tests of each ray is the same as in the
+// packet walk, and so is the result.
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void traverse_lane(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
+                       Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
+  const int n_nodes = sc.n_nodes;
+  int node = active ? 0 : n_nodes;
+  while (__any(node < n_nodes)) {
+    int first = 0, count = 0;
+    while (node < n_nodes && count == 0) {
+      const RO DNode &nd = rdonly(sc.nodes)[node];
+      n_node++;
+      if (box_hit(nd, ray, t_min, closest_t)) {
+        if (nd.first >= 0) {
+          first = nd.first;
+          count = nd.count;
+          node = nd.skip;
+        } else {
+          node = node + 1;
+        }
+      } else {
+        node = nd.skip;
+      }
+    }
+    for (int k = 0; __any(k < count); k++) {
+      if (k < count) {
+        const int pi = rdonly(sc.leaf_prims)[first + k];
+        n_prim++;
+        isect_prim<SHADOW, UV, MOTION>(sc, rdonly(sc.prims)[pi], pi, ray, t_min, closest_t, best);
+      }
+    }
+  }
+}
+
+// PACKET chooses the wave-coherent walk (small scenes, coherent rays) or the per-lane walk.
+template <bool PACKET, bool SHADOW, bool UV, bool MOTION>
+DEV void traverse(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t, Best<UV> &best,
+                  unsigned &n_node, unsigned &n_prim) {
+  if (PACKET) traverse_packet<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
+  else traverse_lane<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
+}
+
 // What shading needs from a hit (HitRecord, HitRecord.h:8-32).
 template <bool UV> struct Surface;
 template <> struct Surface<false> {
@@ -375,7 +421,7 @@ DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int 
 
 // One block of 256 rays: virtual block `vb` of the launch.  `active` and `j` locate the lane's queue
 // entry (unused by PRIMARY, whose virtual blocks are (16x16 pixel block, sample index) pairs).
-template <bool PRIMARY, bool UV, bool MOTION>
+template <bool PRIMARY, bool UV, bool MOTION, bool PACKET>
 DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, unsigned &n_node, unsigned &n_prim) {
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
@@ -432,7 +478,7 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
   park_key[threadIdx.x] = key;
   park_pixel[threadIdx.x] = pixel;
   PARK_FENCE();
-  traverse_packet<false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
+  traverse<PACKET, false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
   PARK_FENCE();
   W = mk(park_w[0][threadIdx.x], park_w[1][threadIdx.x], park_w[2][threadIdx.x]);
   key = park_key[threadIdx.x];
@@ -601,17 +647,17 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 
 // PRIMARY: one grid block per (pixel block, sample).  Otherwise the grid has a fixed size and its
 // blocks stride over the virtual blocks of the input queue, whose length only the device knows.
-template <bool PRIMARY, bool UV, bool MOTION>
+template <bool PRIMARY, bool UV, bool MOTION, bool PACKET>
 __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
   unsigned n_node = 0, n_prim = 0;
   if (PRIMARY) {
-    trace_block<true, UV, MOTION>(a, blockIdx.x, true, 0, n_node, n_prim);
+    trace_block<true, UV, MOTION, PACKET>(a, blockIdx.x, true, 0, n_node, n_prim);
   } else {
     const WaveView v = wave_view(a.in_count, a.in.shard_cap);
     for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
       size_t j;
       const bool active = view_entry(v, vb, a.in.shard_cap, j);
-      trace_block<false, UV, MOTION>(a, vb, active, j, n_node, n_prim);
+      trace_block<false, UV, MOTION, PACKET>(a, vb, active, j, n_node, n_prim);
     }
   }
 #ifndef MIRT_PROFILE
@@ -630,6 +676,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_TRACE_WAVES) void k_trace(
 // parked in LDS and the parts of the work item that are only needed later (colour, pixel, random
 // key, light) stay in memory: the traversal with its inlined intersectors sets the kernel's vector
 // register peak, and every register freed there counts towards one more resident wave per SIMD.
+template <bool PACKET>
 DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_node, unsigned &n_prim,
                       unsigned &n_seg) {
   // per lane: the item (point, colour, key, pixel, light), the light's strata, and the walk state
@@ -711,7 +758,7 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
 #if MIRT_PROFILE == 2
     PROF_MARK(2);
 #endif
-    traverse_packet<true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+    traverse<PACKET, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
 #if MIRT_PROFILE == 2
     PROF_MARK(1);
 #endif
@@ -754,13 +801,14 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
 }
 
 // Fixed-size grid striding over the virtual blocks of the shadow queue.
+template <bool PACKET>
 __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
   const WaveView v = wave_view(a.count, a.shard_cap);
   for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
     size_t slot;
     const bool valid = view_entry(v, vb, a.shard_cap, slot);
-    shadow_block(a, valid, slot, n_node, n_prim, n_seg);
+    shadow_block<PACKET>(a, valid, slot, n_node, n_prim, n_seg);
   }
 #ifndef MIRT_PROFILE
   count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
@@ -796,6 +844,7 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
 
 
 // Closest hit of the pixel-centre camera rays at time 0.5 (pinhole): the parity hook.
+template <bool PACKET>
 __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
   const uint32_t bx = blockIdx.x % ((a.width + 15) / 16), by = blockIdx.x / ((a.width + 15) / 16);
   const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -808,7 +857,7 @@ __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
   BEST_IN_LDS(true, best);
   double closest = 1.7976931348623157e308;
   unsigned nn = 0, np = 0;
-  traverse_packet<false, true, false>(a.sc, ray, active, 1e-5, closest, best, nn, np);
+  traverse<PACKET, false, true, false>(a.sc, ray, active, 1e-5, closest, best, nn, np);
   if (!active) return;
   const size_t i = (size_t)gy * a.width + gx;
   const bool hit = best.prim >= 0;
@@ -828,6 +877,7 @@ __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
 }
 
 // Closest hit of caller-supplied rays (any origin, direction, shutter time, range): parity hook.
+template <bool PACKET>
 __global__ __launch_bounds__(256) void k_trace_rays(const RaysArgs a) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const bool active = i < a.n;
@@ -837,7 +887,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(const RaysArgs a) {
   BEST_IN_LDS(false, best);
   double closest = a.t_max ? a.t_max[j] : 1.7976931348623157e308;
   unsigned nn = 0, np = 0;
-  traverse_packet<false, false, true>(a.sc, ray, active, a.t_min, closest, best, nn, np);
+  traverse<PACKET, false, false, true>(a.sc, ray, active, a.t_min, closest, best, nn, np);
   if (!active) return;
   const bool hit = best.prim >= 0;
   a.prim_id[i] = best.prim;

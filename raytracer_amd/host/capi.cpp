@@ -8,6 +8,7 @@
 
 #include "flatten.h"
 #include "mirt_scene.h"
+#include "synthetic.h"
 
 namespace {
 struct HostScene {
@@ -68,6 +69,20 @@ void *mirt_host_scene_load(const char *path, const char *texture_root) {
   h->scene = load_scene(path ? path : "");
   h->flat = flatten_scene(h->scene, texture_root ? texture_root : "");
   return h;
+}
+
+// The synthetic cloud of make_synthetic_scene(n_prims, seed), flattened.
+void *mirt_host_scene_synthetic(int n_prims, uint64_t seed) {
+  HostScene *h = new (std::nothrow) HostScene;
+  if (!h) return nullptr;
+  h->scene = make_synthetic_scene(n_prims, seed);
+  h->flat = flatten_scene(h->scene, "");
+  return h;
+}
+
+// Writes the handle's scene in the ASCII grammar (sphere / torus / cylinder / cone scenes only).
+int mirt_host_scene_write_ascii(void *handle, const char *path) {
+  return write_scene_ascii(static_cast<HostScene *>(handle)->scene, path ? path : "") ? 0 : -1;
 }
 
 void mirt_host_scene_free(void *handle) { delete static_cast<HostScene *>(handle); }

@@ -15,6 +15,9 @@ def pytest_configure(config):
 FIXTURES = os.path.join(ROOT, "fixtures")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene"]
+# generated scenes (raytracer_amd/host/synthetic.h): name -> (primitives, seed); oracle/make_goldens.py
+# feeds the same scenes to the reference as ASCII files
+SYNTHETIC = {"synthetic100k": (100000, 0x5EED)}
 
 
 def scene_path(name):
@@ -29,18 +32,24 @@ def host_scenes():
 
     def get(name):
         if name not in cache:
-            cache[name] = HostScene(scene_path(name), FIXTURES)
+            if name in SYNTHETIC:
+                cache[name] = HostScene.synthetic(*SYNTHETIC[name])
+            else:
+                cache[name] = HostScene(scene_path(name), FIXTURES)
         return cache[name]
     return get
 
 
 @pytest.fixture(scope="session")
 def device_scenes(host_scenes):
+    """(name, traversal="auto") -> DeviceScene on GPU 0, kept for the session."""
     from raytracer_amd import DeviceScene
     cache = {}
 
-    def get(name):
-        if name not in cache:
-            cache[name] = DeviceScene(host_scenes(name), 0)
-        return cache[name]
+    def get(name, traversal="auto"):
+        if (name, traversal) not in cache:
+            ds = DeviceScene(host_scenes(name), 0)
+            ds.set_traversal(traversal)
+            cache[(name, traversal)] = ds
+        return cache[(name, traversal)]
     return get

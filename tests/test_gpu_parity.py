@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from conftest import GOLDEN, SCENES
+from conftest import GOLDEN, SCENES, SYNTHETIC
 from raytracer_amd import default_config
 
 pytestmark = pytest.mark.gpu
@@ -13,29 +13,46 @@ pytestmark = pytest.mark.gpu
 W, H = 96, 54  # size of the committed golden maps
 
 
-@pytest.mark.parametrize("name", SCENES)
-def test_closest_hit_vs_golden_and_oracle(name, host_scenes, device_scenes):
-    """Primitive id, distance, normal and uv of pixel-centre rays (mirt_trace_ids)."""
-    hs, ds = host_scenes(name), device_scenes(name)
+@pytest.mark.parametrize("traversal", ["packet", "lane"])
+@pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
+def test_closest_hit_vs_golden_and_oracle(name, traversal, host_scenes, device_scenes):
+    """Primitive id, distance, normal and uv of pixel-centre rays (mirt_trace_ids), with either BVH walk."""
+    hs, ds = host_scenes(name), device_scenes(name, traversal)
     cam, _ = hs.camera(0)
     got = ds.trace_ids(cam, W, H)
     gold = np.load(os.path.join(GOLDEN, f"hits_{name}.npz"))
     ref = O.trace_ids(hs.desc, cam, W, H)
     assert np.array_equal(ref["prim_id"], gold["prim_id"])  # the oracle is pinned to the reference
-    agree = float((got["prim_id"] == gold["prim_id"]).mean())
-    print(f"{name}: prim-id agreement {agree:.6f}")
-    assert agree >= 0.9995  # required: >= 0.999
     same = got["prim_id"] == gold["prim_id"]
     hit = same & (gold["prim_id"] >= 0)
-    assert np.allclose(got["t"][hit], gold["t"][hit], rtol=1e-9, atol=1e-9)
-    assert np.allclose(got["normal"][hit], gold["normal"][hit], atol=1e-7)
-    assert np.allclose(got["uv"][hit], gold["uv"][hit], atol=1e-7)
+    # Everything but the torus is arithmetic-for-arithmetic the reference's and must agree to rounding.
+    # The torus quartic runs in x87 long double in the reference and in double here, and the root is
+    # then polished by a Newton iteration that stops at a step of 1e-6 (Torus.cpp:220-254).  For a
+    # torus a few hundredths across seen from hundreds of units away (the generated cloud) even long
+    # double loses the roots, and the reference reports hit points units away from the torus; those
+    # pixels count as disagreements here.
+    kinds = np.array([hs.desc.prims[i].type for i in range(hs.desc.n_prims)] + [-1])
+    torus = kinds[gold["prim_id"]] == 3
+    dt = np.abs(got["t"] - gold["t"])
+    close = np.where(torus, dt <= 2e-5 * np.maximum(1.0, gold["t"]), dt <= 1e-9 * np.maximum(1.0, gold["t"]))
+    assert close[hit & ~torus].all()
+    agree = float((same & (close | ~hit)).mean())
+    print(f"{name}: prim-id agreement {float(same.mean()):.6f}, with distance {agree:.6f}")
+    assert float(same.mean()) >= 0.999  # the required bar
+    assert agree >= 0.998
+    if name not in SYNTHETIC:
+        assert float(same.mean()) >= 0.9995 and close[hit].all()
+    ok = hit & close
+    for sel, tol in ((ok & ~torus, 1e-7), (ok & torus, 2e-3)):
+        assert np.allclose(got["normal"][sel], gold["normal"][sel], atol=tol)
+        assert np.allclose(got["uv"][sel], gold["uv"][sel], atol=tol)
 
 
-@pytest.mark.parametrize("name", SCENES)
-def test_deterministic_render_vs_golden(name, host_scenes, device_scenes):
+@pytest.mark.parametrize("traversal", ["packet", "lane"])
+@pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
+def test_deterministic_render_vs_golden(name, traversal, host_scenes, device_scenes):
     """Pixel-centre, time 0.5, depth 5 trace() colours against the reference's own values."""
-    hs, ds = host_scenes(name), device_scenes(name)
+    hs, ds = host_scenes(name), device_scenes(name, traversal)
     cam, _ = hs.camera(0)
     cfg = default_config(max_ray_depth=5, enable_motion_blur=0, sampling=1, enable_gamma_correction=0)
     gold = np.load(os.path.join(GOLDEN, f"hits_{name}.npz"))["trace_rgb_depth5"].reshape(H, W, 3)
@@ -104,6 +121,22 @@ def test_random_rays_vs_oracle(name, host_scenes, device_scenes):
     ok = (ref["prim_id"] == got["prim_id"]) & (ref["prim_id"] >= 0)
     assert np.allclose(got["t"][ok], ref["t"][ok], rtol=1e-8, atol=1e-9)
     assert np.allclose(got["normal"][ok], ref["normal"][ok], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["t5_glossy", "t7_dof_soft", "t2_texture"])
+def test_lane_walk_renders_what_packet_walk_renders(case, host_scenes, device_scenes):
+    """Same rays, same tests per ray, same addressed draws: the two BVH walks differ only in the
+    order in which the fp64 atomics reach a pixel."""
+    scene, dof, over = RENDER_CASES[case]
+    hs = host_scenes(scene)
+    cam, _ = hs.camera(0, dof=dof)
+    cfg = default_config(**over)
+    a, sa = device_scenes(scene, "packet").render(cam, cfg, 64, 36, 2)
+    b, sb = device_scenes(scene, "lane").render(cam, cfg, 64, 36, 2)
+    assert np.abs(a - b).max() <= 1e-12
+    for k in ("primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
+              "shadow_prim_tests"):
+        assert sa[k] == sb[k], k
 
 
 def test_static_geometry_is_bit_exact(host_scenes, device_scenes):

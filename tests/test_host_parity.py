@@ -135,3 +135,39 @@ def test_cli_exit_codes():
                  "--samples", "--resolution", "--light-intensity", "--ambient-light", "--threads", "--log-level",
                  "--disable-dof", "--disable-motion-blur", "--enable-textures", "--disable-textures", "--output"):
         assert flag in run("--help").stdout
+
+
+def test_synthetic_scene_is_deterministic_and_round_trips(tmp_path):
+    """The generated cloud is a function of (count, seed), has the advertised mix, and reaches the
+    same flat arrays through the ASCII writer + the scene parser as directly."""
+    import ctypes as C
+
+    from raytracer_amd import HostScene
+    from raytracer_amd import _abi as A
+
+    def raw(ptr, n, T):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(T),)).copy()
+
+    def arrays(hs):
+        d = hs.desc
+        return {"nodes": raw(d.nodes, d.n_nodes, A.Node), "prims": raw(d.prims, d.n_prims, A.Prim),
+                "materials": raw(d.materials, d.n_materials, A.Material), "lights": raw(d.lights, d.n_lights, A.Light),
+                "leaf": np.ctypeslib.as_array(d.leaf_prims, shape=(d.n_leaf_prims,)).copy()}
+
+    a, b, c = HostScene.synthetic(2001, 5), HostScene.synthetic(2001, 5), HostScene.synthetic(2001, 6)
+    A1, B1, C1 = arrays(a), arrays(b), arrays(c)
+    assert all(np.array_equal(A1[k], B1[k]) for k in A1)
+    assert not np.array_equal(A1["prims"], C1["prims"])
+    assert a.desc.n_prims == 2001 and a.desc.n_lights == 3 and a.camera_count == 1
+    kinds = np.array([a.desc.prims[i].type for i in range(2001)])
+    assert [int((kinds == k).sum()) for k in (A.MIRT_SPHERE, A.MIRT_TORUS, A.MIRT_CYLINDER, A.MIRT_CONE)] == [501, 500, 500, 500]
+    mats = [a.desc.materials[i] for i in range(2001)]
+    mirrors = sum(m.reflectivity > 0 for m in mats) / 2001
+    glass = sum(m.transparency > 0 for m in mats) / 2001
+    assert 0.15 < mirrors < 0.25 and 0.03 < glass < 0.08
+
+    (tmp_path / "ASCII").mkdir()
+    path = str(tmp_path / "ASCII" / "cloud.txt")
+    a.write_ascii(path)
+    D1 = arrays(HostScene(path, str(tmp_path)))
+    assert all(np.array_equal(A1[k], D1[k]) for k in A1)
