@@ -3,6 +3,7 @@
 fixtures/ASCII/Test5.txt at 1920x1080, 16 spp, max-depth 5 (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --config cfg3|cfg4|cfg5        (the other BASELINE.json configurations)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -69,20 +70,50 @@ def cpu_baseline(scene_name, width, height, spp, depth, rays_per_sample):
         return {"value": None, "unit": "Mrays/s", "cores": cores, "kind": "unavailable", "sample": str(e)}
 
 
+# BASELINE.json configs[1..4]: argument defaults per preset (explicit flags still override)
+PRESETS = {
+    "cfg2": dict(scene="Test5", width=1920, height=1080, spp=16, max_depth=5),
+    "cfg3": dict(scene="Test5", width=1920, height=1080, spp=16, max_depth=8, soft_shadows=16, glossy_reflection=8),
+    "cfg4": dict(scene="synthetic:1000000", width=3840, height=2160, spp=16, max_depth=5),
+    "cfg5": dict(scene="Test7_glass", width=1920, height=1080, spp=64, max_depth=8, soft_shadows=16,
+                 glossy_reflection=4, depth_of_field=[0.95, 16.12]),
+}
+
+
+def hbm_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json, written by
+    profiles/traffic_summary.py from rocprofv3 FETCH_SIZE / WRITE_SIZE passes), if it is for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if t.get("workload") == workload and kernel in t.get("kernels", {}):
+            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=sorted(PRESETS), default="cfg2")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default="Test5")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=16)
-    ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--scene", default=None, help="scene under fixtures/ASCII, or synthetic:<primitives>")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--soft-shadows", type=int, default=None)
-    ap.add_argument("--glossy-reflection", type=int, default=0)
+    ap.add_argument("--glossy-reflection", type=int, default=None)
+    ap.add_argument("--depth-of-field", type=float, nargs=2, default=None, metavar=("FSTOP", "FOCUS"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    for k, v in PRESETS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.glossy_reflection is None:
+        args.glossy_reflection = 0
 
     import torch
     import torch.distributed as dist
@@ -103,9 +134,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    hs = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{args.scene}.txt"))
+    if args.scene.startswith("synthetic:"):
+        hs = HostScene.synthetic(int(args.scene.split(":")[1]))
+    else:
+        hs = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{args.scene}.txt"))
     ds = DeviceScene(hs, local_rank)
-    cam, _ = hs.camera(0)
+    cam, _ = hs.camera(0, dof=tuple(args.depth_of_field) if args.depth_of_field else None)
     over = dict(max_ray_depth=args.max_depth, glossy_samples=args.glossy_reflection)
     if args.soft_shadows is not None:
         over["shadow_samples"] = args.soft_shadows
@@ -179,8 +213,13 @@ def main():
         b_ray = bytes_per_ray(nn / max(q, 1), npr / max(q, 1))
         avg_ms = ms / max(launches, 1)
         achieved = (q / max(launches, 1)) * b_ray / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        workload = (f"{args.scene} {W}x{H} {spp}spp max-depth {args.max_depth} motion-blur on"
+                    + (f" glossy {args.glossy_reflection}" if args.glossy_reflection else "")
+                    + (f" soft-shadows {args.soft_shadows}" if args.soft_shadows is not None else "")
+                    + (f" dof {args.depth_of_field[0]} {args.depth_of_field[1]}" if args.depth_of_field else ""))
+        traffic = hbm_traffic(name, workload) if world == 1 else None
         line = {
-            "metric": "Mrays/s (primary+secondary) at 1920x1080x16spp depth 5",
+            "metric": f"Mrays/s (primary+secondary) at {W}x{H}x{spp}spp depth {args.max_depth}",
             "value": rays_ps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -192,20 +231,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.scene} {W}x{H} {spp}spp max-depth {args.max_depth} motion-blur on"
-                                   + (f" glossy {args.glossy_reflection}" if args.glossy_reflection else "")
-                                   + (f" soft-shadows {args.soft_shadows}" if args.soft_shadows is not None else ""),
-                       "tile": tile if world > 1 else None, "parallelism": f"tiles/{world}"},
+            "config": {"workload": workload, "preset": args.config, "tile": tile if world > 1 else None,
+                       "parallelism": f"tiles/{world}"},
             "mrays_all_per_s": rays_all / elapsed / 1e6,
             "rays_per_sample": rays_ps / max(tot["primary_rays"], 1),
             "shadow_segments_per_sample": tot["shadow_segments"] / max(tot["primary_rays"], 1),
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "node_tests_per_ray": nn / max(q, 1),
                          "prim_tests_per_ray": npr / max(q, 1), "rays_per_launch": q / max(launches, 1),
                          "avg_launch_ms": avg_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline(args.scene, W // 2, H // 2, spp, args.max_depth, line["rays_per_sample"])
         print(json.dumps(line), flush=True)
     if world > 1:

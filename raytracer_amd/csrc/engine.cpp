@@ -439,10 +439,10 @@ MIRT_API void mirt_scene_destroy(mirt_scene *scene) {
 MIRT_API int mirt_scene_set_traversal(mirt_scene *scene, int mode) {
   if (!scene) return fail(MIRT_ERR_INVALID, "NULL scene");
   if (mode == MIRT_TRAVERSAL_AUTO) {
-    // the packet walk visits the union of its 64 rays' paths: best while the tree is a handful of
-    // nodes (MIRT_TRAVERSAL=packet|lane overrides the choice for experiments)
+    // the packet walk visits the union of its 64 rays' paths: measured faster up to several hundred
+    // primitives, slower from about a thousand (MIRT_TRAVERSAL=packet|lane overrides the choice)
     const char *env = std::getenv("MIRT_TRAVERSAL");
-    scene->packet = (size_t)scene->n_prims <= env_size("MIRT_PACKET_MAX_PRIMS", 64);
+    scene->packet = (size_t)scene->n_prims <= env_size("MIRT_PACKET_MAX_PRIMS", 512);
     if (env && std::strcmp(env, "packet") == 0) scene->packet = true;
     if (env && std::strcmp(env, "lane") == 0) scene->packet = false;
   } else if (mode == MIRT_TRAVERSAL_PACKET || mode == MIRT_TRAVERSAL_LANE) {
