@@ -191,6 +191,7 @@ typedef struct mirt_stats {
   double shadow_kernel_ms;   /* sum of HIP-event durations of the shadow launches */
   uint64_t trace_kernel_launches;
   uint64_t shadow_kernel_launches;
+  uint64_t frame_attempts; /* 1, plus one for every time the frame was redone with finer launches because a queue overflowed */
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene;
@@ -244,10 +245,13 @@ int mirt_trace_rays(mirt_scene *scene, int64_t n, const double *origin, const do
                     const double *time, double t_min, const double *t_max, int32_t *prim_id, double *t,
                     double *normal);
 
-/* Engine tuning, no counterpart in the reference: how rays walk the BVH.  Both walks test the same
- * boxes and primitives in the same order per ray (Bvh.cpp:306-333) and return the same hits.
- * MIRT_TRAVERSAL_AUTO picks by scene size (packet for scenes of a few dozen primitives). */
-enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE = 2 };
+/* Engine tuning, no counterpart in the reference: how rays walk the BVH.
+ * PACKET (one node index per wave) and LANE (one per ray) test the same boxes and primitives in the
+ * same order per ray as intersect_bvh (Bvh.cpp:306-333) and return the same hits, exact ties included.
+ * ORDERED (per ray, nearer child first, farther child on a per-lane stack) tests fewer boxes; it
+ * returns the same closest hit except that two surfaces at exactly the same distance may swap.
+ * AUTO: PACKET up to a few hundred primitives, LANE above. */
+enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE = 2, MIRT_TRAVERSAL_ORDERED = 3 };
 int mirt_scene_set_traversal(mirt_scene *scene, int mode);
 
 const char *mirt_last_error(void);

@@ -80,7 +80,8 @@ class Stats(C.Structure):
                 ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("shadow_node_tests", C.c_uint64),
                 ("shadow_prim_tests", C.c_uint64), ("launches", C.c_uint64),
                 ("device_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
-                ("trace_kernel_launches", C.c_uint64), ("shadow_kernel_launches", C.c_uint64)]
+                ("trace_kernel_launches", C.c_uint64), ("shadow_kernel_launches", C.c_uint64),
+                ("frame_attempts", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

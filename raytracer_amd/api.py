@@ -121,8 +121,9 @@ class DeviceScene:
         self.device = device
 
     def set_traversal(self, mode):
-        """mode: "auto", "packet" (wave-coherent BVH walk) or "lane" (one walk per ray)."""
-        code = {"auto": 0, "packet": 1, "lane": 2}[mode]
+        """mode: "auto", "packet" (wave-coherent BVH walk), "lane" (one walk per ray, the reference's
+        order) or "ordered" (one walk per ray, nearer child first)."""
+        code = {"auto": 0, "packet": 1, "lane": 2, "ordered": 3}[mode]
         _check(self._lib.mirt_scene_set_traversal(self._h, code), "mirt_scene_set_traversal")
 
     def close(self):

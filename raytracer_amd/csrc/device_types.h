@@ -24,10 +24,14 @@ struct alignas(64) DNode {
   double bmax[3];
   int32_t skip;   // next node in depth-first order after this subtree
   int32_t first;  // leaf: first entry in leaf_prims; inner node: -1
-  int32_t count;  // leaf: number of primitives
-  int32_t pad;
+  int32_t count;  // leaf: number of primitives; inner node: index of the second child (the first is this + 1)
+  int32_t order;  // inner node: bits 0-1 axis along which the children lie furthest apart, bit 2: second child is the lower one
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte record");
+
+// BVH walks (see pipeline.h)
+enum : int32_t { WALK_PACKET = 0, WALK_LANE = 1, WALK_ORDERED = 2 };
+#define WALK_STACK 24  // entries of the ordered walk's per-lane stack: the tree may be this deep at most
 
 struct alignas(64) DPrim {
   int32_t type;
@@ -207,11 +211,11 @@ struct RaysArgs {
 };
 
 // Launchers defined in kernels.hip (the only translation unit compiled for the GPU).
-// packet: wave-coherent BVH walk (one node index per wave) instead of the per-lane walk;
+// walk: WALK_* (wave-coherent, per lane in the reference's order, per lane nearer child first);
 // uv: the scene samples image maps, so hits carry texture coordinates and a tangent frame;
 // motion: some ray of the launch may be at a shutter time other than 0.5.
-void launch_trace(bool packet, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
-void launch_shadow(bool packet, unsigned grid, void *stream, const ShadowArgs &a);
+void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
+void launch_shadow(int walk, unsigned grid, void *stream, const ShadowArgs &a);
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a);
-void launch_trace_ids(bool packet, unsigned grid, void *stream, const IdsArgs &a);
-void launch_trace_rays(bool packet, unsigned grid, void *stream, const RaysArgs &a);
+void launch_trace_ids(int walk, unsigned grid, void *stream, const IdsArgs &a);
+void launch_trace_rays(int walk, unsigned grid, void *stream, const RaysArgs &a);

@@ -4,50 +4,62 @@
 
 #include "pipeline.h"
 
-template <bool PRIMARY, bool UV, bool MOTION, bool PACKET>
+template <bool PRIMARY, bool UV, bool MOTION, int WALK>
 static void launch_trace_t(unsigned grid, hipStream_t st, const TraceArgs &a) {
-  hipLaunchKernelGGL((k_trace<PRIMARY, UV, MOTION, PACKET>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((k_trace<PRIMARY, UV, MOTION, WALK>), dim3(grid), dim3(256), 0, st, a);
 }
 
-template <bool PACKET>
-static void launch_trace_p(bool primary, bool uv, bool motion, unsigned grid, hipStream_t st, const TraceArgs &a) {
+template <int WALK>
+static void launch_trace_w(bool primary, bool uv, bool motion, unsigned grid, hipStream_t st, const TraceArgs &a) {
   const int v = (primary ? 4 : 0) | (uv ? 2 : 0) | (motion ? 1 : 0);
   switch (v) {
-    case 0: launch_trace_t<false, false, false, PACKET>(grid, st, a); break;
-    case 1: launch_trace_t<false, false, true, PACKET>(grid, st, a); break;
-    case 2: launch_trace_t<false, true, false, PACKET>(grid, st, a); break;
-    case 3: launch_trace_t<false, true, true, PACKET>(grid, st, a); break;
-    case 4: launch_trace_t<true, false, false, PACKET>(grid, st, a); break;
-    case 5: launch_trace_t<true, false, true, PACKET>(grid, st, a); break;
-    case 6: launch_trace_t<true, true, false, PACKET>(grid, st, a); break;
-    default: launch_trace_t<true, true, true, PACKET>(grid, st, a); break;
+    case 0: launch_trace_t<false, false, false, WALK>(grid, st, a); break;
+    case 1: launch_trace_t<false, false, true, WALK>(grid, st, a); break;
+    case 2: launch_trace_t<false, true, false, WALK>(grid, st, a); break;
+    case 3: launch_trace_t<false, true, true, WALK>(grid, st, a); break;
+    case 4: launch_trace_t<true, false, false, WALK>(grid, st, a); break;
+    case 5: launch_trace_t<true, false, true, WALK>(grid, st, a); break;
+    case 6: launch_trace_t<true, true, false, WALK>(grid, st, a); break;
+    default: launch_trace_t<true, true, true, WALK>(grid, st, a); break;
   }
 }
 
-void launch_trace(bool packet, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a) {
+// Dispatch on the walk: WALK_PACKET, WALK_LANE, anything else WALK_ORDERED.
+#define BY_WALK(walk, call_packet, call_lane, call_ordered) \
+  do {                                                       \
+    if ((walk) == WALK_PACKET) call_packet;                  \
+    else if ((walk) == WALK_LANE) call_lane;                 \
+    else call_ordered;                                       \
+  } while (0)
+
+void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (packet) launch_trace_p<true>(primary, uv, motion, grid, st, a);
-  else launch_trace_p<false>(primary, uv, motion, grid, st, a);
+  BY_WALK(walk, launch_trace_w<WALK_PACKET>(primary, uv, motion, grid, st, a),
+          launch_trace_w<WALK_LANE>(primary, uv, motion, grid, st, a),
+          launch_trace_w<WALK_ORDERED>(primary, uv, motion, grid, st, a));
 }
 
-void launch_shadow(bool packet, unsigned grid, void *stream, const ShadowArgs &a) {
+void launch_shadow(int walk, unsigned grid, void *stream, const ShadowArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (packet) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(256), 0, st, a);
+  BY_WALK(walk, hipLaunchKernelGGL(k_shadow<WALK_PACKET>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_shadow<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_shadow<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a));
 }
 
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a) {
   hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
 }
 
-void launch_trace_ids(bool packet, unsigned grid, void *stream, const IdsArgs &a) {
+void launch_trace_ids(int walk, unsigned grid, void *stream, const IdsArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (packet) hipLaunchKernelGGL(k_trace_ids<true>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_trace_ids<false>, dim3(grid), dim3(256), 0, st, a);
+  BY_WALK(walk, hipLaunchKernelGGL(k_trace_ids<WALK_PACKET>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_trace_ids<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_trace_ids<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a));
 }
 
-void launch_trace_rays(bool packet, unsigned grid, void *stream, const RaysArgs &a) {
+void launch_trace_rays(int walk, unsigned grid, void *stream, const RaysArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (packet) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(256), 0, st, a);
+  BY_WALK(walk, hipLaunchKernelGGL(k_trace_rays<WALK_PACKET>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_trace_rays<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_trace_rays<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a));
 }

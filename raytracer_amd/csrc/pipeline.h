@@ -164,12 +164,60 @@ DEV void traverse_lane(const DScene &sc, const RayL &ray, bool active, double t_
   }
 }
 
-// PACKET chooses the wave-coherent walk (small scenes, coherent rays) or the per-lane walk.
-template <bool PACKET, bool SHADOW, bool UV, bool MOTION>
+// Per-lane walk that descends into the nearer child first and keeps the farther one on a per-lane
+// stack in LDS: the closest hit is found early and most of the far subtrees are then culled by their
+// box test against it.  The reference's walk has no such order (Bvh.cpp:322-332), which on a deep
+// tree costs it several times as many box tests for the same answer.  "Nearer" is decided by the sign
+// of the ray direction along the axis on which the two children lie furthest apart.  The closest
+// hit does not depend on the visiting order except when two surfaces are hit at exactly the same
+// distance, where the one tested later can win (each intersector has its own rule for equality).
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
+                          Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
+  __shared__ int32_t stack[WALK_STACK][256];
+  const int tid = threadIdx.x;
+  int sp = 0;
+  int node = active ? 0 : -1;
+  while (__any(node >= 0)) {
+    int first = 0, count = 0;
+    while (node >= 0 && count == 0) {
+      const RO DNode &nd = rdonly(sc.nodes)[node];
+      n_node++;
+      int next = -1;
+      if (box_hit(nd, ray, t_min, closest_t)) {
+        if (nd.first >= 0) {
+          first = nd.first;
+          count = nd.count;
+        } else {
+          const int axis = nd.order & 3;
+          const double d = comp(ray.d, axis);
+          // second child first when it is the lower one and the ray runs upwards, or the reverse
+          const bool second_first = ((nd.order & 4) != 0) == (d >= 0.0);
+          next = second_first ? nd.count : node + 1;
+          stack[sp++][tid] = second_first ? node + 1 : nd.count;
+        }
+      }
+      if (next < 0 && sp > 0) next = stack[--sp][tid];
+      node = next;
+    }
+    for (int k = 0; __any(k < count); k++) {
+      if (k < count) {
+        const int pi = rdonly(sc.leaf_prims)[first + k];
+        n_prim++;
+        isect_prim<SHADOW, UV, MOTION>(sc, rdonly(sc.prims)[pi], pi, ray, t_min, closest_t, best);
+      }
+    }
+  }
+}
+
+// WALK: WALK_PACKET (small scenes, coherent rays), WALK_LANE (per lane, the reference's order) or
+// WALK_ORDERED (per lane, nearer child first).
+template <int WALK, bool SHADOW, bool UV, bool MOTION>
 DEV void traverse(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t, Best<UV> &best,
                   unsigned &n_node, unsigned &n_prim) {
-  if (PACKET) traverse_packet<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
-  else traverse_lane<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
+  if (WALK == WALK_PACKET) traverse_packet<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
+  else if (WALK == WALK_LANE) traverse_lane<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
+  else traverse_ordered<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
 }
 
 // What shading needs from a hit (HitRecord, HitRecord.h:8-32).
@@ -421,7 +469,7 @@ DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int 
 
 // One block of 256 rays: virtual block `vb` of the launch.  `active` and `j` locate the lane's queue
 // entry (unused by PRIMARY, whose virtual blocks are (16x16 pixel block, sample index) pairs).
-template <bool PRIMARY, bool UV, bool MOTION, bool PACKET>
+template <bool PRIMARY, bool UV, bool MOTION, int WALK>
 DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, unsigned &n_node, unsigned &n_prim) {
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
@@ -478,7 +526,7 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
   park_key[threadIdx.x] = key;
   park_pixel[threadIdx.x] = pixel;
   PARK_FENCE();
-  traverse<PACKET, false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
+  traverse<WALK, false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
   PARK_FENCE();
   W = mk(park_w[0][threadIdx.x], park_w[1][threadIdx.x], park_w[2][threadIdx.x]);
   key = park_key[threadIdx.x];
@@ -647,17 +695,17 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 
 // PRIMARY: one grid block per (pixel block, sample).  Otherwise the grid has a fixed size and its
 // blocks stride over the virtual blocks of the input queue, whose length only the device knows.
-template <bool PRIMARY, bool UV, bool MOTION, bool PACKET>
+template <bool PRIMARY, bool UV, bool MOTION, int WALK>
 __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
   unsigned n_node = 0, n_prim = 0;
   if (PRIMARY) {
-    trace_block<true, UV, MOTION, PACKET>(a, blockIdx.x, true, 0, n_node, n_prim);
+    trace_block<true, UV, MOTION, WALK>(a, blockIdx.x, true, 0, n_node, n_prim);
   } else {
     const WaveView v = wave_view(a.in_count, a.in.shard_cap);
     for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
       size_t j;
       const bool active = view_entry(v, vb, a.in.shard_cap, j);
-      trace_block<false, UV, MOTION, PACKET>(a, vb, active, j, n_node, n_prim);
+      trace_block<false, UV, MOTION, WALK>(a, vb, active, j, n_node, n_prim);
     }
   }
 #ifndef MIRT_PROFILE
@@ -676,7 +724,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_TRACE_WAVES) void k_trace(
 // parked in LDS and the parts of the work item that are only needed later (colour, pixel, random
 // key, light) stay in memory: the traversal with its inlined intersectors sets the kernel's vector
 // register peak, and every register freed there counts towards one more resident wave per SIMD.
-template <bool PACKET>
+template <int WALK>
 DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_node, unsigned &n_prim,
                       unsigned &n_seg) {
   // per lane: the item (point, colour, key, pixel, light), the light's strata, and the walk state
@@ -758,7 +806,7 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
 #if MIRT_PROFILE == 2
     PROF_MARK(2);
 #endif
-    traverse<PACKET, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+    traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
 #if MIRT_PROFILE == 2
     PROF_MARK(1);
 #endif
@@ -801,14 +849,14 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
 }
 
 // Fixed-size grid striding over the virtual blocks of the shadow queue.
-template <bool PACKET>
+template <int WALK>
 __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
   const WaveView v = wave_view(a.count, a.shard_cap);
   for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
     size_t slot;
     const bool valid = view_entry(v, vb, a.shard_cap, slot);
-    shadow_block<PACKET>(a, valid, slot, n_node, n_prim, n_seg);
+    shadow_block<WALK>(a, valid, slot, n_node, n_prim, n_seg);
   }
 #ifndef MIRT_PROFILE
   count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
@@ -844,7 +892,7 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
 
 
 // Closest hit of the pixel-centre camera rays at time 0.5 (pinhole): the parity hook.
-template <bool PACKET>
+template <int WALK>
 __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
   const uint32_t bx = blockIdx.x % ((a.width + 15) / 16), by = blockIdx.x / ((a.width + 15) / 16);
   const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -857,7 +905,7 @@ __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
   BEST_IN_LDS(true, best);
   double closest = 1.7976931348623157e308;
   unsigned nn = 0, np = 0;
-  traverse<PACKET, false, true, false>(a.sc, ray, active, 1e-5, closest, best, nn, np);
+  traverse<WALK, false, true, false>(a.sc, ray, active, 1e-5, closest, best, nn, np);
   if (!active) return;
   const size_t i = (size_t)gy * a.width + gx;
   const bool hit = best.prim >= 0;
@@ -877,7 +925,7 @@ __global__ __launch_bounds__(256) void k_trace_ids(const IdsArgs a) {
 }
 
 // Closest hit of caller-supplied rays (any origin, direction, shutter time, range): parity hook.
-template <bool PACKET>
+template <int WALK>
 __global__ __launch_bounds__(256) void k_trace_rays(const RaysArgs a) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const bool active = i < a.n;
@@ -887,7 +935,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(const RaysArgs a) {
   BEST_IN_LDS(false, best);
   double closest = a.t_max ? a.t_max[j] : 1.7976931348623157e308;
   unsigned nn = 0, np = 0;
-  traverse<PACKET, false, false, true>(a.sc, ray, active, a.t_min, closest, best, nn, np);
+  traverse<WALK, false, false, true>(a.sc, ray, active, a.t_min, closest, best, nn, np);
   if (!active) return;
   const bool hit = best.prim >= 0;
   a.prim_id[i] = best.prim;

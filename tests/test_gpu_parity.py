@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 W, H = 96, 54  # size of the committed golden maps
 
 
-@pytest.mark.parametrize("traversal", ["packet", "lane"])
+@pytest.mark.parametrize("traversal", ["packet", "lane", "ordered"])
 @pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
 def test_closest_hit_vs_golden_and_oracle(name, traversal, host_scenes, device_scenes):
     """Primitive id, distance, normal and uv of pixel-centre rays (mirt_trace_ids), with either BVH walk."""
@@ -48,10 +48,16 @@ def test_closest_hit_vs_golden_and_oracle(name, traversal, host_scenes, device_s
         assert np.allclose(got["uv"][sel], gold["uv"][sel], atol=tol)
 
 
-@pytest.mark.parametrize("traversal", ["packet", "lane"])
+@pytest.mark.parametrize("traversal", ["packet", "lane", "ordered"])
 @pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
 def test_deterministic_render_vs_golden(name, traversal, host_scenes, device_scenes):
     """Pixel-centre, time 0.5, depth 5 trace() colours against the reference's own values."""
+    if traversal == "ordered" and name in ("Test4", "Test6"):
+        # these two scenes have coincident surfaces (a glass cylinder standing on the ground plane, ...):
+        # which of two hits at exactly the same distance wins depends on the order of the tests, and
+        # the ordered walk -- chosen automatically only for scenes of more than 512 primitives -- does
+        # not keep the reference's order
+        pytest.skip("exact ties are order dependent")
     hs, ds = host_scenes(name), device_scenes(name, traversal)
     cam, _ = hs.camera(0)
     cfg = default_config(max_ray_depth=5, enable_motion_blur=0, sampling=1, enable_gamma_correction=0)
@@ -137,6 +143,29 @@ def test_lane_walk_renders_what_packet_walk_renders(case, host_scenes, device_sc
     for k in ("primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
               "shadow_prim_tests"):
         assert sa[k] == sb[k], k
+
+
+def test_small_queues_split_the_frame_without_changing_it(host_scenes, monkeypatch):
+    """With queues far too small for the frame the engine cuts it into many primary launches, renders
+    it again with finer launches when a queue shard overflows anyway, and returns the same frame."""
+    hs = host_scenes("Test4")  # mirrors and glass: with 8 glossy samples some hits spawn 10 rays
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=6, glossy_samples=8)
+    w, h, spp = 320, 180, 4
+    want, st0 = DeviceScene(hs, 0).render(cam, cfg, w, h, spp)
+    monkeypatch.setenv("MIRT_RAY_QUEUE", "65536")
+    monkeypatch.setenv("MIRT_SHADOW_QUEUE", "262144")
+    small = DeviceScene(hs, 0)
+    got, st1 = small.render(cam, cfg, w, h, spp)
+    again, st2 = small.render(cam, cfg, w, h, spp)  # the split found for this frame shape is remembered
+    print("launches", st0["launches"], st1["launches"], st2["launches"], "attempts", st1["frame_attempts"],
+          st2["frame_attempts"], "rays per sample", (st0["primary_rays"] + st0["secondary_rays"]) / st0["primary_rays"])
+    assert st0["frame_attempts"] == 1 and st1["frame_attempts"] > 1 and st2["frame_attempts"] == 1
+    assert st1["launches"] > 4 * st0["launches"]
+    for got_i, st in ((got, st1), (again, st2)):
+        assert np.abs(got_i - want).max() <= 1e-12
+        for k in ("primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests"):
+            assert st[k] == st0[k], k
 
 
 def test_static_geometry_is_bit_exact(host_scenes, device_scenes):
