@@ -9,6 +9,10 @@ fixtures/ASCII/Test5.txt at 1920x1080, 16 spp, max-depth 5 (BASELINE.json config
 
 A step is one frame.  With N > 1 each rank renders the interleaved 16x16 tiles it owns from its own
 replica of the scene and the frame is all-gathered (RCCL); the gather is inside the timed region.
+Two frames are kept in flight (mirt_render_tiles_begin / _end on two streams): frame i + 1 is enqueued
+before the host waits for frame i, so the launch latencies of one frame's small deep-level launches
+are covered by the other frame's work.  Every frame of the timed region is complete, gather included,
+before the clock stops.  --frames-in-flight 1 renders them one after the other.
 Rank 0 prints one JSON line.  `value` counts the rays all ranks traced per second of the slowest
 rank's wall time, with the scene already resident in HBM.
 """
@@ -108,6 +112,7 @@ def main():
     ap.add_argument("--glossy-reflection", type=int, default=None)
     ap.add_argument("--depth-of-field", type=float, nargs=2, default=None, metavar=("FSTOP", "FOCUS"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, choices=(1, 2), default=2)
     args = ap.parse_args()
     for k, v in PRESETS[args.config].items():
         if getattr(args, k) is None:
@@ -143,49 +148,72 @@ def main():
     over = dict(max_ray_depth=args.max_depth, glossy_samples=args.glossy_reflection)
     if args.soft_shadows is not None:
         over["shadow_samples"] = args.soft_shadows
-    # per-kernel HIP events (for the roofline entry) cost ~10 us per launch: kept on at N = 1, where the
-    # frame is long; at N > 1 the timed region runs without them and one extra frame after it is timed
-    # per kernel
-    over["kernel_timing"] = 1 if world == 1 else 0
+    # per-kernel HIP events (for the roofline entry) cost ~10 us per launch and, with two frames in
+    # flight, would time kernels that share the GPU with the other frame's: the timed region runs
+    # without them, and the kernels are timed on frames rendered one at a time right after it
+    over["kernel_timing"] = 0
     cfg = default_config(**over)
     W, H, spp, tile = args.width, args.height, args.spp, D.TILE
 
+    depth = args.frames_in_flight
     if world > 1:
-        local = D.local_buffer(W, H, tile, tile, world, device)
+        bufs = [D.local_buffer(W, H, tile, tile, world, device) for _ in range(depth)]
     else:
-        local = torch.empty(W * H * 3, dtype=torch.float64, device=device)
-    stream = torch.cuda.current_stream(device).cuda_stream
+        bufs = [torch.empty(W * H * 3, dtype=torch.float64, device=device) for _ in range(depth)]
+    streams = [torch.cuda.Stream(device) for _ in range(depth)]
+    frames = [None] * depth
 
-    def step():
+    def begin(slot):
+        """Enqueues one frame (this rank's tiles, then the gather) on the slot's stream."""
+        s = streams[slot]
         if world > 1:
-            st = ds.render_tiles(cam, cfg, W, H, spp, tile, tile, rank, world, local.data_ptr(), stream)
-            frame = D.gather_frame(local, W, H, tile, tile)
+            ds.render_tiles_begin(cam, cfg, W, H, spp, tile, tile, rank, world, bufs[slot].data_ptr(), s.cuda_stream, slot)
+            with torch.cuda.stream(s):
+                frames[slot] = D.gather_frame(bufs[slot], W, H, tile, tile)
         else:
-            st = ds.render_tiles(cam, cfg, W, H, spp, W, H, 0, 1, local.data_ptr(), stream)
-            frame = local.view(H, W, 3)
-        return frame, st
+            ds.render_tiles_begin(cam, cfg, W, H, spp, W, H, 0, 1, bufs[slot].data_ptr(), s.cuda_stream, slot)
+            frames[slot] = bufs[slot].view(H, W, 3)
+
+    def end(slot):
+        """Waits for the slot's frame; returns its stats."""
+        st = ds.render_tiles_end(slot)
+        if st["frame_attempts"] > 1 and world > 1:  # the frame was redone after the gather had been enqueued
+            with torch.cuda.stream(streams[slot]):
+                frames[slot] = D.gather_frame(bufs[slot], W, H, tile, tile)
+        return st
+
+    def run(n, depth=depth):
+        """n frames, `depth` of them in flight; returns the summed stats."""
+        acc = None
+        for i in range(n + depth):
+            slot = i % depth
+            if i >= depth:
+                st = end(slot)
+                acc = st if acc is None else {k: acc[k] + st[k] for k in st}
+            if i < n:
+                begin(slot)
+        for s in streams:
+            s.synchronize()
+        return acc
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    acc = None
+    if args.warmup:
+        run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame, st = step()
-        acc = st if acc is None else {k: acc[k] + st[k] for k in st}
+    acc = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        cfg.kernel_timing = 1
-        _, st = step()
-        for k in ("trace_kernel_ms", "shadow_kernel_ms", "trace_kernel_launches", "shadow_kernel_launches"):
-            acc[k] = st[k] * args.steps
-        barrier()
+    cfg.kernel_timing = 1
+    n_timed = args.steps if world == 1 else 1
+    st = run(n_timed, depth=1)
+    for k in ("trace_kernel_ms", "shadow_kernel_ms", "trace_kernel_launches", "shadow_kernel_launches"):
+        acc[k] = st[k] * (args.steps / n_timed)
+    barrier()
 
     keys = ["primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
             "shadow_prim_tests", "trace_kernel_launches", "shadow_kernel_launches"]
@@ -232,7 +260,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "preset": args.config, "tile": tile if world > 1 else None,
-                       "parallelism": f"tiles/{world}"},
+                       "parallelism": f"tiles/{world}", "frames_in_flight": depth},
             "mrays_all_per_s": rays_all / elapsed / 1e6,
             "rays_per_sample": rays_ps / max(tot["primary_rays"], 1),
             "shadow_segments_per_sample": tot["shadow_segments"] / max(tot["primary_rays"], 1),
@@ -240,7 +268,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "node_tests_per_ray": nn / max(q, 1),
                          "prim_tests_per_ray": npr / max(q, 1), "rays_per_launch": q / max(launches, 1),
-                         "avg_launch_ms": avg_ms},
+                         "avg_launch_ms": avg_ms,
+                         "timed_on": f"{n_timed} frame(s) rendered one at a time after the timed region"},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline(args.scene, W // 2, H // 2, spp, args.max_depth, line["rays_per_sample"])

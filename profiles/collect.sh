@@ -1,7 +1,9 @@
 #!/bin/bash
 # Collects the profiles of one bench configuration on the GPU box:
 #   [PASSES="bench stats 1 2 3 4 5 6"] profiles/collect.sh <tag> [bench.py flags...]
-# writes gpurun_out/<tag>/{bench.json, stats/, pmc1..4/}.  Each counter pass is a run of its own.
+# writes gpurun_out/<tag>/{bench.json, stats/, pmc1..6/}.  Each counter pass is a run of its own.  The profiled
+# runs render one frame at a time (--frames-in-flight 1), like the frames bench.py times its kernels on, so that
+# kernel durations are not stretched by another frame's kernels sharing the GPU.
 set -e -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
 TAG=$1; shift
@@ -14,12 +16,12 @@ if want bench; then
 fi
 cd /tmp && export TMPDIR=/tmp
 if want stats; then
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline "$@" > "$O/stats.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --frames-in-flight 1 "$@" > "$O/stats.log" 2>&1
 fi
 pass() {
   local n=$1; shift
   want "$n" || return 0
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$O/pmc$n" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > "$O/pmc$n.log" 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$O/pmc$n" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 "${BENCH_ARGS[@]}" > "$O/pmc$n.log" 2>&1
 }
 BENCH_ARGS=("$@")
 pass 1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU

@@ -89,7 +89,7 @@ class Stats(C.Structure):
 
 ENGINE_SYMBOLS = [
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
-    "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal",
+    "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal", "mirt_render_tiles_begin", "mirt_render_tiles_end",
     "mirt_last_error", "mirt_abi_version",
 ]
 
@@ -106,6 +106,9 @@ def _declare_engine(lib):
                                 dp, C.POINTER(Stats)]
     lib.mirt_render_tiles.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Config), C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    lib.mirt_render_tiles_begin.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Config), C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.mirt_render_tiles_end.argtypes = [C.c_void_p, C.c_int, C.POINTER(Stats)]
     lib.mirt_tile_buffer_pixels.argtypes = [C.c_int] * 6
     lib.mirt_tile_buffer_pixels.restype = C.c_int64
     lib.mirt_trace_ids.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, dp]

@@ -153,6 +153,20 @@ class DeviceScene:
                                            C.byref(st)), "mirt_render_tiles")
         return st.as_dict()
 
+    def render_tiles_begin(self, camera, config, width, height, spp, tile_w, tile_h, rank, world, out_ptr, stream,
+                           slot):
+        """Enqueues this rank's tiles on `stream` with working-memory set `slot` (0 or 1) and returns
+        without waiting (mirt_render_tiles_begin)."""
+        _check(self._lib.mirt_render_tiles_begin(self._h, C.byref(camera), C.byref(config), width, height, spp,
+                                                 tile_w, tile_h, rank, world, C.c_void_p(out_ptr),
+                                                 C.c_void_p(stream or 0), slot), "mirt_render_tiles_begin")
+
+    def render_tiles_end(self, slot):
+        """Waits for the frame of `slot`; returns its stats (frame_attempts > 1: it was rendered again)."""
+        st = A.Stats()
+        _check(self._lib.mirt_render_tiles_end(self._h, slot, C.byref(st)), "mirt_render_tiles_end")
+        return st.as_dict()
+
     def trace_ids(self, camera, width, height):
         n = width * height
         ids = np.empty(n, dtype=np.int32)

@@ -90,6 +90,11 @@ struct RayQueueMem {
   RayQueueMem &operator=(const RayQueueMem &) = delete;
 };
 
+struct Timed {
+  hipEvent_t a, b;
+  int kind;  // 0 trace, 1 shadow
+};
+
 // which kinds of ray-spawning materials the scene has (decides the most children one hit can have)
 struct SpawnKinds {
   bool mirror = false, lobe = false, glass = false, mirror_glass = false, lobe_glass = false;
@@ -108,22 +113,39 @@ struct mirt_scene {
   std::vector<DeviceBuffer> texels;
   std::vector<mirt_light> host_lights;
   SpawnKinds kinds;
-  // per-frame working memory, grown on demand and kept
-  RayQueueMem queues[2];  // rays of even / odd depth: a depth reads one and appends to the other
-  DeviceBuffer shadow_items, control, accum, out, ids;  // control: statistics counters, then the queue tails
-  char *pinned = nullptr;  // read-back of the tail counters and the statistics
-  size_t pinned_bytes = 0;
-  size_t ray_shard_cap = 0, shadow_shard_cap = 0;  // entries per queue shard
+  // Per-frame working memory, grown on demand and kept.  Two sets, so that a second frame can be
+  // enqueued (mirt_render_tiles_begin) while the first is still running.
+  struct WorkSet {
+    RayQueueMem queues[2];  // rays of even / odd depth: a depth reads one and appends to the other
+    DeviceBuffer shadow_items, control, accum;  // control: statistics counters, then the queue tails
+    char *pinned = nullptr;  // read-back of the control block
+    size_t pinned_bytes = 0;
+    size_t ray_shard_cap = 0, shadow_shard_cap = 0;  // entries per queue shard
+    bool accum_clean = false;  // the accumulation buffer is all zero (k_resolve leaves it so)
+    size_t accum_clean_bytes = 0;
+    std::vector<hipEvent_t> events;
+    // the frame in flight
+    bool pending = false;
+    mirt_camera camera{};
+    mirt_config config{};
+    int width = 0, height = 0, spp = 0, tile_w = 0, tile_h = 0, rank = 0, world = 1;
+    double *d_out = nullptr;
+    hipStream_t stream = nullptr;
+    size_t chunks = 0, control_bytes = 0;
+    uint64_t per_launch = 0, launches = 0, attempts = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<Timed> timed;
+    ~WorkSet() {
+      for (auto e : events) (void)hipEventDestroy(e);
+      if (pinned) (void)hipHostFree(pinned);
+    }
+  } work[2];
+  DeviceBuffer out, ids;
   uint64_t split_for = 0;  // frame shape (primary grid blocks, depth, glossy samples) `split` was found for
+  uint32_t split = 1;      // primary launches are cut this many times finer than the queues' sizes suggest
   int light_frame_for = 0;  // shadow_samples the device copy of the lights' strata was made for
   bool light_frame_valid = false;
-  bool accum_clean = false;  // the accumulation buffer is all zero (k_resolve leaves it so)
-  size_t accum_clean_bytes = 0;
-  uint32_t split = 1;      // primary launches are cut this many times finer than the queues' sizes suggest
-  std::vector<hipEvent_t> events;
   ~mirt_scene() {
-    for (auto e : events) (void)hipEventDestroy(e);
-    if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -332,7 +354,7 @@ int max_children(const SpawnKinds &k, int glossy_samples) {
 
 constexpr size_t kCountBytes = (size_t)QUEUE_SHARDS * QUEUE_COUNT_STRIDE * sizeof(uint32_t);
 
-hipError_t ensure_queue(mirt_scene *sc, int which) {
+hipError_t ensure_queue(mirt_scene::WorkSet *sc, int which) {
   RayQueueMem &rq = sc->queues[which];
   const size_t cap = sc->ray_shard_cap * QUEUE_SHARDS;
   if (rq.q.shard_cap == sc->ray_shard_cap && rq.mem.p) return hipSuccess;
@@ -351,7 +373,7 @@ hipError_t ensure_queue(mirt_scene *sc, int which) {
   return hipSuccess;
 }
 
-hipError_t ensure_pinned(mirt_scene *sc, size_t bytes) {
+hipError_t ensure_pinned(mirt_scene::WorkSet *sc, size_t bytes) {
   if (bytes <= sc->pinned_bytes) return hipSuccess;
   if (sc->pinned) (void)hipHostFree(sc->pinned);
   sc->pinned = nullptr;
@@ -394,12 +416,7 @@ DCamera device_camera(const mirt_camera &c, int width, int height) {
   return d;
 }
 
-struct Timed {
-  hipEvent_t a, b;
-  int kind;  // 0 trace, 1 shadow
-};
-
-hipError_t get_event(mirt_scene *sc, size_t &used, hipEvent_t &e) {
+hipError_t get_event(mirt_scene::WorkSet *sc, size_t &used, hipEvent_t &e) {
   if (used == sc->events.size()) {
     hipEvent_t n;
     hipError_t err = hipEventCreate(&n);
@@ -600,22 +617,21 @@ MIRT_API int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int 
 
 namespace {
 
-// One frame (or this rank's tiles of it) into a device buffer.
-int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *config, int width, int height,
-                  int spp, int tile_w, int tile_h, int rank, int world, double *d_out, hipStream_t stream,
-                  mirt_stats *stats) {
-  if (!sc || !camera || !config || !d_out) return fail(MIRT_ERR_INVALID, "NULL argument");
-  if (width <= 0 || height <= 0 || spp <= 0) return fail(MIRT_ERR_INVALID, "width, height and spp must be positive");
-  if (tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world)
-    return fail(MIRT_ERR_INVALID, "bad tile split: tile %dx%d rank %d of %d", tile_w, tile_h, rank, world);
-  if ((double)width * height * spp > 4.0e9) return fail(MIRT_ERR_UNSUPPORTED, "more than 4e9 samples in one frame");
-  HIP_TRY(hipSetDevice(sc->device));
-  if (!stream) stream = sc->stream;
-
+// Geometry of one rank's share of a frame.
+struct FrameShape {
   DFrame fr;
+  size_t n_pixels;
+  uint64_t total_blocks;  // 16x16 pixel blocks of this rank's tiles
+  int64_t tiles;
+};
+
+FrameShape frame_shape(const mirt_camera &camera, const mirt_config &config, int width, int height, int spp, int tile_w,
+                       int tile_h, int rank, int world) {
+  FrameShape f;
+  DFrame &fr = f.fr;
   std::memset(&fr, 0, sizeof fr);
-  fr.cam = device_camera(*camera, width, height);
-  fr.cfg = *config;
+  fr.cam = device_camera(camera, width, height);
+  fr.cfg = config;
   fr.width = width;
   fr.height = height;
   fr.spp = spp;
@@ -627,28 +643,45 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   fr.world = world;
   fr.blocks_x = (tile_w + 15) / 16;
   fr.blocks_y = (tile_h + 15) / 16;
-  const int64_t tiles = (int64_t)fr.tiles_x * fr.tiles_y;
-  fr.n_slots = (int32_t)(tiles > rank ? (tiles - rank + world - 1) / world : 0);
-  const size_t n_pixels = (size_t)fr.n_slots * tile_w * tile_h;
-  const uint64_t total_blocks = (uint64_t)fr.n_slots * fr.blocks_x * fr.blocks_y;
+  f.tiles = (int64_t)fr.tiles_x * fr.tiles_y;
+  fr.n_slots = (int32_t)(f.tiles > rank ? (f.tiles - rank + world - 1) / world : 0);
+  f.n_pixels = (size_t)fr.n_slots * tile_w * tile_h;
+  f.total_blocks = (uint64_t)fr.n_slots * fr.blocks_x * fr.blocks_y;
+  return f;
+}
+
+// Enqueues the frame recorded in `ws` on its stream: fills, every launch of every depth, resolve and
+// the read-back of the control block.  Nothing here waits for the device.
+int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
+  const mirt_config *config = &ws->config;
+  const int spp = ws->spp;
+  hipStream_t stream = ws->stream;
+  FrameShape shape = frame_shape(ws->camera, ws->config, ws->width, ws->height, spp, ws->tile_w, ws->tile_h, ws->rank,
+                                 ws->world);
+  DFrame &fr = shape.fr;
+  const size_t n_pixels = shape.n_pixels;
+  const uint64_t total_blocks = shape.total_blocks;
 
   // shadow strata per light for this frame (Raytracer.cpp:146-158)
   const int n_lights = sc->d.n_lights;
-  std::vector<DLightFrame> lf(n_lights);
-  uint32_t dim = MIRT_DIM_SHADOW;
-  for (int l = 0; l < n_lights; ++l) {
-    const mirt_light &L = sc->host_lights[l];
-    int samples = (L.type == MIRT_LIGHT_AREA) ? std::max(1, L.samples) : 1;
-    if (config->shadow_samples > 0 && L.type == MIRT_LIGHT_AREA) samples = config->shadow_samples;
-    int side = static_cast<int>(std::sqrt(samples));
-    if (side * side == 0) side = 1;
-    lf[l].dim = dim;
-    lf[l].side = side;
-    lf[l].inv_n = 1.0 / (side * side);
-    dim += 2u * (uint32_t)(side * side);
-  }
   if (n_lights && (sc->light_frame_for != config->shadow_samples || !sc->light_frame_valid)) {
-    // blocking copy from pageable memory: done once per shadow_samples value, not per frame
+    std::vector<DLightFrame> lf(n_lights);
+    uint32_t dim = MIRT_DIM_SHADOW;
+    for (int l = 0; l < n_lights; ++l) {
+      const mirt_light &L = sc->host_lights[l];
+      int samples = (L.type == MIRT_LIGHT_AREA) ? std::max(1, L.samples) : 1;
+      if (config->shadow_samples > 0 && L.type == MIRT_LIGHT_AREA) samples = config->shadow_samples;
+      int side = static_cast<int>(std::sqrt(samples));
+      if (side * side == 0) side = 1;
+      lf[l].dim = dim;
+      lf[l].side = side;
+      lf[l].inv_n = 1.0 / (side * side);
+      dim += 2u * (uint32_t)(side * side);
+    }
+    // blocking copy from pageable memory: done once per shadow_samples value, not per frame; frames
+    // in flight may still read the old table
+    for (auto &w : sc->work)
+      if (w.pending) HIP_TRY(hipStreamSynchronize(w.stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(sc->light_frame.p, lf.data(), sizeof(DLightFrame) * n_lights, hipMemcpyHostToDevice));
     sc->light_frame_for = config->shadow_samples;
@@ -675,189 +708,198 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   want_s = std::max(std::min(want_s, shard_blocks * 256 * S * std::max(K, 1)), min_blocks * 256 * S);
   if (want_r * QUEUE_SHARDS > 0xfffffff0u || want_s * QUEUE_SHARDS > 0xfffffff0u)
     return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
-  if (want_r > sc->ray_shard_cap) sc->ray_shard_cap = want_r;
-  if (want_s > sc->shadow_shard_cap) sc->shadow_shard_cap = want_s;
-  HIP_TRY(sc->shadow_items.reserve(sc->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem)));
+  if (want_r > ws->ray_shard_cap) ws->ray_shard_cap = want_r;
+  if (want_s > ws->shadow_shard_cap) ws->shadow_shard_cap = want_s;
+  HIP_TRY(ws->shadow_items.reserve(ws->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem)));
   {
-    const void *before = sc->accum.p;
-    HIP_TRY(sc->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
-    if (sc->accum.p != before) sc->accum_clean = false;
+    const void *before = ws->accum.p;
+    HIP_TRY(ws->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
+    if (ws->accum.p != before) ws->accum_clean = false;
   }
   if (levels > 1) {
-    HIP_TRY(ensure_queue(sc, 0));
-    HIP_TRY(ensure_queue(sc, 1));
+    HIP_TRY(ensure_queue(ws, 0));
+    HIP_TRY(ensure_queue(ws, 1));
   }
   // grid of the launches that consume a queue: fixed, the blocks stride over the queue
   const unsigned consumer_grid = (unsigned)std::min<size_t>(
       env_size("MIRT_CONSUMER_BLOCKS", 4096),
-      (size_t)QUEUE_SHARDS * ((std::max(sc->ray_shard_cap, sc->shadow_shard_cap) + 255) / 256));
+      (size_t)QUEUE_SHARDS * ((std::max(ws->ray_shard_cap, ws->shadow_shard_cap) + 255) / 256));
 
-  const uint64_t shape = grid_total * 1000003ull + (uint64_t)levels * 1009ull + (uint64_t)config->glossy_samples;
-  if (sc->split_for != shape) {
-    sc->split_for = shape;
+  const uint64_t shape_key = grid_total * 1000003ull + (uint64_t)levels * 1009ull + (uint64_t)config->glossy_samples;
+  if (sc->split_for != shape_key) {
+    sc->split_for = shape_key;
     sc->split = 1;
   }
   const bool uv = sc->d.any_maps && config->enable_textures;
   const bool motion = sc->d.any_motion && config->enable_motion_blur && config->sampling == MIRT_SAMPLING_JITTER;
 
+  // pixel blocks per primary launch
+  const uint64_t fit =
+      (uint64_t)QUEUE_SHARDS * std::min(ws->shadow_shard_cap / (256 * (size_t)S), ws->ray_shard_cap / (size_t)256);
+  const uint64_t per_launch = std::max<uint64_t>(1, fit / (uint64_t)spp / sc->split);
+  const size_t chunks = total_blocks ? (size_t)((total_blocks + per_launch - 1) / per_launch) : 0;
+  // tail counters: per primary launch and level, the rays and the shadow items that level queued
+  const size_t stats_bytes = COUNTER_SHARDS * sizeof(DCounters);
+  const size_t control_bytes = stats_bytes + chunks * (size_t)std::max(levels, 0) * 2 * kCountBytes;
+  HIP_TRY(ws->control.reserve(control_bytes));
+  HIP_TRY(ensure_pinned(ws, control_bytes));
+  DCounters *counters = ws->control.as<DCounters>();
+  auto tails = [&](size_t chunk, int level, int what) {  // what: 0 rays, 1 shadow items
+    return reinterpret_cast<uint32_t *>(ws->control.as<char>() + stats_bytes +
+                                        ((chunk * (size_t)levels + (size_t)level) * 2 + (size_t)what) * kCountBytes);
+  };
+  const bool kernel_timing = config->kernel_timing != 0;
+
   size_t ev_used = 0;
-  std::vector<Timed> timed;
-  hipEvent_t ev_begin, ev_end;
-  uint64_t launches = 0, secondary = 0, primary = 0, attempts = 0;
-  const DCounters *host_counters = nullptr;
+  ws->timed.clear();
+  ws->launches = 0;
+  ws->attempts++;
+  ws->chunks = chunks;
+  ws->control_bytes = control_bytes;
+  ws->per_launch = per_launch;
+  HIP_TRY(get_event(ws, ev_used, ws->ev_begin));
+  HIP_TRY(get_event(ws, ev_used, ws->ev_end));
+  HIP_TRY(hipEventRecord(ws->ev_begin, stream));
+  HIP_TRY(hipMemsetAsync(ws->control.p, 0, control_bytes, stream));
+  if (n_pixels && !(ws->accum_clean && ws->accum_clean_bytes >= n_pixels * 3 * sizeof(double)))
+    HIP_TRY(hipMemsetAsync(ws->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
+  ws->accum_clean = false;
 
-  for (;;) {
-    // pixel blocks per primary launch
-    const uint64_t fit = (uint64_t)QUEUE_SHARDS *
-                         std::min(sc->shadow_shard_cap / (256 * (size_t)S), sc->ray_shard_cap / (size_t)256);
-    const uint64_t per_launch = std::max<uint64_t>(1, fit / (uint64_t)spp / sc->split);
-    const size_t chunks = total_blocks ? (size_t)((total_blocks + per_launch - 1) / per_launch) : 0;
-    // tail counters: per primary launch and level, the rays and the shadow items that level queued
-    const size_t stats_bytes = COUNTER_SHARDS * sizeof(DCounters);
-    const size_t control_bytes = stats_bytes + chunks * (size_t)std::max(levels, 0) * 2 * kCountBytes;
-    HIP_TRY(sc->control.reserve(control_bytes));
-    HIP_TRY(ensure_pinned(sc, control_bytes));
-    DCounters *counters = sc->control.as<DCounters>();
-    auto tails = [&](size_t chunk, int level, int what) {  // what: 0 rays, 1 shadow items
-      return reinterpret_cast<uint32_t *>(sc->control.as<char>() + stats_bytes +
-                                          ((chunk * (size_t)levels + (size_t)level) * 2 + (size_t)what) * kCountBytes);
-    };
-    const bool kernel_timing = config->kernel_timing != 0;
-
-    ev_used = 0;
-    timed.clear();
-    launches = 0;
-    attempts++;
-    HIP_TRY(get_event(sc, ev_used, ev_begin));
-    HIP_TRY(get_event(sc, ev_used, ev_end));
-    HIP_TRY(hipEventRecord(ev_begin, stream));
-    HIP_TRY(hipMemsetAsync(sc->control.p, 0, control_bytes, stream));
-    if (n_pixels && !(sc->accum_clean && sc->accum_clean_bytes >= n_pixels * 3 * sizeof(double)))
-      HIP_TRY(hipMemsetAsync(sc->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
-    sc->accum_clean = false;
-
-    for (size_t c = 0; c < chunks && levels > 0; ++c) {
-      const uint64_t b0 = c * per_launch;
-      const uint32_t nb = (uint32_t)std::min<uint64_t>(per_launch, total_blocks - b0);
-      for (int depth = 0; depth < levels; ++depth) {
-        const bool spawn = depth + 1 < levels;
-        TraceArgs a;
-        std::memset(&a, 0, sizeof a);
-        a.sc = sc->d;
-        a.fr = fr;
-        if (depth > 0) {
-          a.in = sc->queues[depth & 1].q;
-          a.in_count = tails(c, depth - 1, 0);
-        }
-        if (spawn) {
-          a.out = sc->queues[(depth + 1) & 1].q;
-          a.out_count = tails(c, depth, 0);
-        }
-        a.shadow = sc->shadow_items.as<DShadowItem>();
-        a.shadow_count = tails(c, depth, 1);
-        a.shadow_shard_cap = (uint32_t)sc->shadow_shard_cap;
-        a.accum = sc->accum.as<double>();
-        a.counters = counters;
-        a.first = (uint32_t)b0;
-        a.n = nb;
-        a.depth = depth;
-        Timed t{nullptr, nullptr, 0};
-        if (kernel_timing) {
-          HIP_TRY(get_event(sc, ev_used, t.a));
-          HIP_TRY(get_event(sc, ev_used, t.b));
-          HIP_TRY(hipEventRecord(t.a, stream));
-        }
-        const unsigned grid = depth == 0 ? nb * (unsigned)spp : consumer_grid;
-        launch_trace(sc->walk, depth == 0, uv, motion, grid, stream, a);
-        {
-          const hipError_t le = hipGetLastError();
-          if (le != hipSuccess)
-            return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u): %s", depth, grid, hipGetErrorString(le));
-        }
-        if (kernel_timing) {
-          HIP_TRY(hipEventRecord(t.b, stream));
-          timed.push_back(t);
-        }
-
-        ShadowArgs sa;
-        std::memset(&sa, 0, sizeof sa);
-        sa.sc = sc->d;
-        sa.fr = fr;
-        sa.items = sc->shadow_items.as<DShadowItem>();
-        sa.count = a.shadow_count;
-        sa.shard_cap = (uint32_t)sc->shadow_shard_cap;
-        sa.accum = sc->accum.as<double>();
-        sa.counters = counters;
-        Timed ts{nullptr, nullptr, 1};
-        if (kernel_timing) {
-          HIP_TRY(get_event(sc, ev_used, ts.a));
-          HIP_TRY(get_event(sc, ev_used, ts.b));
-          HIP_TRY(hipEventRecord(ts.a, stream));
-        }
-        launch_shadow(sc->walk, consumer_grid, stream, sa);
-        HIP_TRY(hipGetLastError());
-        if (kernel_timing) {
-          HIP_TRY(hipEventRecord(ts.b, stream));
-          timed.push_back(ts);
-        }
-        launches += 2;
+  for (size_t c = 0; c < chunks && levels > 0; ++c) {
+    const uint64_t b0 = c * per_launch;
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(per_launch, total_blocks - b0);
+    for (int depth = 0; depth < levels; ++depth) {
+      const bool spawn = depth + 1 < levels;
+      TraceArgs a;
+      std::memset(&a, 0, sizeof a);
+      a.sc = sc->d;
+      a.fr = fr;
+      if (depth > 0) {
+        a.in = ws->queues[depth & 1].q;
+        a.in_count = tails(c, depth - 1, 0);
       }
-    }
+      if (spawn) {
+        a.out = ws->queues[(depth + 1) & 1].q;
+        a.out_count = tails(c, depth, 0);
+      }
+      a.shadow = ws->shadow_items.as<DShadowItem>();
+      a.shadow_count = tails(c, depth, 1);
+      a.shadow_shard_cap = (uint32_t)ws->shadow_shard_cap;
+      a.accum = ws->accum.as<double>();
+      a.counters = counters;
+      a.first = (uint32_t)b0;
+      a.n = nb;
+      a.depth = depth;
+      Timed t{nullptr, nullptr, 0};
+      if (kernel_timing) {
+        HIP_TRY(get_event(ws, ev_used, t.a));
+        HIP_TRY(get_event(ws, ev_used, t.b));
+        HIP_TRY(hipEventRecord(t.a, stream));
+      }
+      const unsigned grid = depth == 0 ? nb * (unsigned)spp : consumer_grid;
+      launch_trace(sc->walk, depth == 0, uv, motion, grid, stream, a);
+      {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+          return fail(MIRT_ERR_DEVICE, "trace launch (depth %d, grid %u): %s", depth, grid, hipGetErrorString(le));
+      }
+      if (kernel_timing) {
+        HIP_TRY(hipEventRecord(t.b, stream));
+        ws->timed.push_back(t);
+      }
 
-    if (n_pixels) {
-      ResolveArgs r;
-      std::memset(&r, 0, sizeof r);
-      r.accum = sc->accum.as<double>();
-      r.out = d_out;
-      r.n_pixels = (uint32_t)n_pixels;
-      r.spp = spp;
-      r.cfg = *config;
-      launch_resolve((unsigned)((n_pixels + 255) / 256), stream, r);
+      ShadowArgs sa;
+      std::memset(&sa, 0, sizeof sa);
+      sa.sc = sc->d;
+      sa.fr = fr;
+      sa.items = ws->shadow_items.as<DShadowItem>();
+      sa.count = a.shadow_count;
+      sa.shard_cap = (uint32_t)ws->shadow_shard_cap;
+      sa.accum = ws->accum.as<double>();
+      sa.counters = counters;
+      Timed ts{nullptr, nullptr, 1};
+      if (kernel_timing) {
+        HIP_TRY(get_event(ws, ev_used, ts.a));
+        HIP_TRY(get_event(ws, ev_used, ts.b));
+        HIP_TRY(hipEventRecord(ts.a, stream));
+      }
+      launch_shadow(sc->walk, consumer_grid, stream, sa);
       HIP_TRY(hipGetLastError());
-      launches++;
-      sc->accum_clean = true;  // k_resolve zeroes what it reads
-      sc->accum_clean_bytes = n_pixels * 3 * sizeof(double);
+      if (kernel_timing) {
+        HIP_TRY(hipEventRecord(ts.b, stream));
+        ws->timed.push_back(ts);
+      }
+      ws->launches += 2;
     }
-    HIP_TRY(hipEventRecord(ev_end, stream));
-    HIP_TRY(hipMemcpyAsync(sc->pinned, sc->control.p, control_bytes, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    host_counters = reinterpret_cast<const DCounters *>(sc->pinned);
+  }
 
+  if (n_pixels) {
+    ResolveArgs r;
+    std::memset(&r, 0, sizeof r);
+    r.accum = ws->accum.as<double>();
+    r.out = ws->d_out;
+    r.n_pixels = (uint32_t)n_pixels;
+    r.spp = spp;
+    r.cfg = *config;
+    launch_resolve((unsigned)((n_pixels + 255) / 256), stream, r);
+    HIP_TRY(hipGetLastError());
+    ws->launches++;
+    ws->accum_clean = true;  // k_resolve zeroes what it reads
+    ws->accum_clean_bytes = n_pixels * 3 * sizeof(double);
+  }
+  HIP_TRY(hipEventRecord(ws->ev_end, stream));
+  HIP_TRY(hipMemcpyAsync(ws->pinned, ws->control.p, control_bytes, hipMemcpyDeviceToHost, stream));
+  ws->pending = true;
+  return MIRT_OK;
+}
+
+// Waits for the frame in `ws`.  If a queue shard overflowed, the frame is rendered again with finer
+// primary launches until it fits.  Fills *stats.
+int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
+  if (!ws->pending) return fail(MIRT_ERR_INVALID, "no frame in flight in this slot");
+  const int levels = ws->config.max_ray_depth;
+  const size_t stats_bytes = COUNTER_SHARDS * sizeof(DCounters);
+  uint64_t secondary = 0;
+  for (;;) {
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    ws->pending = false;
     // did every queue shard hold what was appended to it?
     bool overflow = false;
     secondary = 0;
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(sc->pinned + stats_bytes);
-    for (size_t c = 0; c < chunks; ++c)
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(ws->pinned + stats_bytes);
+    for (size_t c = 0; c < ws->chunks; ++c)
       for (int level = 0; level < levels; ++level)
         for (int s = 0; s < QUEUE_SHARDS; ++s) {
           const size_t at = ((c * (size_t)levels + (size_t)level) * 2) * (kCountBytes / sizeof(uint32_t)) +
                             (size_t)s * QUEUE_COUNT_STRIDE;
           const uint32_t rays = words[at], items = words[at + kCountBytes / sizeof(uint32_t)];
-          if (rays > sc->ray_shard_cap || items > sc->shadow_shard_cap) overflow = true;
+          if (rays > ws->ray_shard_cap || items > ws->shadow_shard_cap) overflow = true;
           secondary += rays;
         }
     if (!overflow) break;
-    if (per_launch == 1)
+    if (ws->per_launch == 1)
       return fail(MIRT_ERR_MEMORY,
                   "ray queues too small for this frame even one pixel block at a time; raise MIRT_RAY_QUEUE / "
                   "MIRT_SHADOW_QUEUE (entries)");
     sc->split *= 2;  // render the frame again with finer primary launches
-  }
-
-  if (levels > 0 && total_blocks > 0) {
-    primary = (uint64_t)width * height * spp;
-    if (world > 1 || tile_w != width || tile_h != height) {
-      // samples of the pixels this rank owns
-      uint64_t px = 0;
-      for (int64_t t = rank; t < tiles; t += world) {
-        const int tx = (int)(t % fr.tiles_x), ty = (int)(t / fr.tiles_x);
-        px += (uint64_t)std::min(tile_w, width - tx * tile_w) * std::min(tile_h, height - ty * tile_h);
-      }
-      primary = px * spp;
-    }
+    if (int rc = enqueue_frame(sc, ws)) return rc;
   }
 
   if (stats) {
+    const DCounters *host_counters = reinterpret_cast<const DCounters *>(ws->pinned);
+    const FrameShape shape = frame_shape(ws->camera, ws->config, ws->width, ws->height, ws->spp, ws->tile_w, ws->tile_h,
+                                         ws->rank, ws->world);
+    uint64_t primary = 0;
+    if (levels > 0 && shape.total_blocks > 0) {
+      // samples of the pixels this rank owns
+      uint64_t px = 0;
+      for (int64_t t = ws->rank; t < shape.tiles; t += ws->world) {
+        const int tx = (int)(t % shape.fr.tiles_x), ty = (int)(t / shape.fr.tiles_x);
+        px += (uint64_t)std::min(ws->tile_w, ws->width - tx * ws->tile_w) *
+              std::min(ws->tile_h, ws->height - ty * ws->tile_h);
+      }
+      primary = px * (uint64_t)ws->spp;
+    }
     std::memset(stats, 0, sizeof *stats);
     DCounters c;
     std::memset(&c, 0, sizeof c);
@@ -875,12 +917,12 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
     stats->prim_tests = c.prim_tests;
     stats->shadow_node_tests = c.shadow_node_tests;
     stats->shadow_prim_tests = c.shadow_prim_tests;
-    stats->launches = launches;
-    stats->frame_attempts = attempts;
+    stats->launches = ws->launches;
+    stats->frame_attempts = ws->attempts;
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    HIP_TRY(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
     stats->device_ms = ms;
-    for (const Timed &t : timed) {
+    for (const Timed &t : ws->timed) {
       HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
       if (t.kind == 0) {
         stats->trace_kernel_ms += ms;
@@ -894,7 +936,57 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
   return MIRT_OK;
 }
 
+// Records a frame in work set `slot` and enqueues it.
+int begin_frame(mirt_scene *sc, int slot, const mirt_camera *camera, const mirt_config *config, int width, int height,
+                int spp, int tile_w, int tile_h, int rank, int world, double *d_out, hipStream_t stream) {
+  if (!sc || !camera || !config || !d_out) return fail(MIRT_ERR_INVALID, "NULL argument");
+  if (slot < 0 || slot > 1) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
+  if (width <= 0 || height <= 0 || spp <= 0) return fail(MIRT_ERR_INVALID, "width, height and spp must be positive");
+  if (tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world)
+    return fail(MIRT_ERR_INVALID, "bad tile split: tile %dx%d rank %d of %d", tile_w, tile_h, rank, world);
+  if ((double)width * height * spp > 4.0e9) return fail(MIRT_ERR_UNSUPPORTED, "more than 4e9 samples in one frame");
+  mirt_scene::WorkSet *ws = &sc->work[slot];
+  if (ws->pending) return fail(MIRT_ERR_INVALID, "slot %d still holds a frame: call mirt_render_tiles_end first", slot);
+  HIP_TRY(hipSetDevice(sc->device));
+  ws->camera = *camera;
+  ws->config = *config;
+  ws->width = width;
+  ws->height = height;
+  ws->spp = spp;
+  ws->tile_w = tile_w;
+  ws->tile_h = tile_h;
+  ws->rank = rank;
+  ws->world = world;
+  ws->d_out = d_out;
+  ws->stream = stream ? stream : sc->stream;
+  ws->attempts = 0;
+  return enqueue_frame(sc, ws);
+}
+
+// One frame (or this rank's tiles of it) into a device buffer, start to finish.
+int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *config, int width, int height,
+                  int spp, int tile_w, int tile_h, int rank, int world, double *d_out, hipStream_t stream,
+                  mirt_stats *stats) {
+  if (int rc = begin_frame(sc, 0, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_out, stream))
+    return rc;
+  return finish_frame(sc, &sc->work[0], stats);
+}
+
 }  // namespace
+
+MIRT_API int mirt_render_tiles_begin(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
+                                     int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
+                                     double *d_rgb_out, void *stream, int slot) {
+  return begin_frame(scene, slot, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
+                     static_cast<hipStream_t>(stream));
+}
+
+MIRT_API int mirt_render_tiles_end(mirt_scene *scene, int slot, mirt_stats *stats) {
+  if (!scene) return fail(MIRT_ERR_INVALID, "NULL scene");
+  if (slot < 0 || slot > 1) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
+  HIP_TRY(hipSetDevice(scene->device));
+  return finish_frame(scene, &scene->work[slot], stats);
+}
 
 MIRT_API int mirt_render_tiles(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
                                int height, int spp, int tile_w, int tile_h, int rank, int world, double *d_rgb_out,

@@ -168,6 +168,30 @@ def test_small_queues_split_the_frame_without_changing_it(host_scenes, monkeypat
             assert st[k] == st0[k], k
 
 
+def test_two_frames_in_flight_equal_two_frames_in_turn(host_scenes, device_scenes):
+    """mirt_render_tiles_begin / _end with both working-memory sets busy on two streams."""
+    import torch
+    hs, ds = host_scenes("Test5"), device_scenes("Test5")
+    cam, _ = hs.camera(0)
+    w, h, spp = 160, 90, 2
+    cfgs = [default_config(max_ray_depth=5, seed=11), default_config(max_ray_depth=5, seed=12, glossy_samples=4)]
+    want = [ds.render(cam, c, w, h, spp) for c in cfgs]
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    bufs = [torch.empty(w * h * 3, dtype=torch.float64, device=dev) for _ in range(2)]
+    for rounds in range(3):  # the sets are reused frame after frame
+        for k in range(2):
+            ds.render_tiles_begin(cam, cfgs[k], w, h, spp, w, h, 0, 1, bufs[k].data_ptr(), streams[k].cuda_stream, k)
+        for k in (1, 0):
+            st = ds.render_tiles_end(k)
+            got = bufs[k].cpu().numpy().reshape(h, w, 3)
+            assert np.abs(got - want[k][0]).max() <= 1e-12
+            for key in ("primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests"):
+                assert st[key] == want[k][1][key], key
+    with pytest.raises(RuntimeError):
+        ds.render_tiles_end(0)  # nothing in flight
+
+
 def test_static_geometry_is_bit_exact(host_scenes, device_scenes):
     """Distances and normals of every primitive kind but the torus equal the reference's bit for
     bit (device arithmetic is not contracted into FMAs and keeps the reference's order)."""
