@@ -594,15 +594,13 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 #endif
   // per-light unshadowed Blinn-Phong terms -> shadow work items (Raytracer.cpp:262-286).  A light
   // that faces away from the shading normal adds exactly zero in the reference, so it gets no item.
-  // First pass counts the wave's items so that ONE atomic reserves room for all of them.
+  // First pass counts the wave's items so that ONE atomic reserves room for all of them; it decides
+  // "faces the light" on the un-normalised direction (same sign as the reference's N.L up to the last
+  // rounding of a product that is then of the order of 1e-16 anyway) and the second pass keeps to it.
   {
     uint32_t total = 0;
     for (int li = 0; li < sc.n_lights; li++) {
-      bool push = false;
-      if (hit && lit) {
-        const d3 to = ld3(rdonly(sc.lights)[li].location) - sf.p;
-        push = maxd(0.0, dot(sn, to / len(to))) > 0.0;
-      }
+      const bool push = hit && lit && dot(sn, ld3(rdonly(sc.lights)[li].location) - sf.p) > 0.0;
       total += (uint32_t)__popcll(__ballot(push));
     }
     if (total) {
@@ -612,21 +610,18 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
       const unsigned long long below = (1ull << __lane_id()) - 1ull;
       for (int li = 0; li < sc.n_lights; li++) {
         const RO mirt_light &L = rdonly(sc.lights)[li];
-        bool push = false;
         d3 c = mk(0, 0, 0);
-        if (hit && lit) {
-          const d3 to = ld3(L.location) - sf.p;
+        const d3 to = ld3(L.location) - sf.p;
+        const bool push = hit && lit && dot(sn, to) > 0.0;
+        if (push) {
           const double dist = len(to);
           const d3 ldir = to / dist;
           const double ndl = maxd(0.0, dot(sn, ldir));
-          if (ndl > 0.0) {
-            const d3 lin = ld3(L.color) * (L.intensity * cfg.light_intensity_factor / (dist * dist));
-            c = wd * (tint * ndl) * lin;
-            const d3 half = unit(ldir + (-ray.d));
-            const double ndh = maxd(0.0, dot(sn, half));
-            if (ndh > 0.0) c = c + ws * (ld3(m.specular) * pow(ndh, m.shininess)) * lin;
-            push = true;
-          }
+          const d3 lin = ld3(L.color) * (L.intensity * cfg.light_intensity_factor / (dist * dist));
+          c = wd * (tint * ndl) * lin;
+          const d3 half = unit(ldir + (-ray.d));
+          const double ndh = maxd(0.0, dot(sn, half));
+          if (ndh > 0.0) c = c + ws * (ld3(m.specular) * pow(ndh, m.shininess)) * lin;
         }
         const unsigned long long mask = __ballot(push);
         const uint32_t r = base + (uint32_t)__popcll(mask & below);
