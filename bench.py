@@ -8,7 +8,7 @@ fixtures/ASCII/Test5.txt at 1920x1080, 16 spp, max-depth 5 (BASELINE.json config
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step is one frame.  With N > 1 each rank renders the interleaved 16x16 tiles it owns from its own
-replica of the scene and the frame is all-gathered (RCCL); the gather is inside the timed region.
+replica of the scene and the frame is gathered to rank 0 (RCCL); the gather is inside the timed region.
 Two frames are kept in flight (mirt_render_tiles_begin / _end on two streams): frame i + 1 is enqueued
 before the host waits for frame i, so the launch latencies of one frame's small deep-level launches
 are covered by the other frame's work.  Every frame of the timed region is complete, gather included,
@@ -169,7 +169,7 @@ def main():
         if world > 1:
             ds.render_tiles_begin(cam, cfg, W, H, spp, tile, tile, rank, world, bufs[slot].data_ptr(), s.cuda_stream, slot)
             with torch.cuda.stream(s):
-                frames[slot] = D.gather_frame(bufs[slot], W, H, tile, tile)
+                frames[slot] = D.gather_frame(bufs[slot], W, H, tile, tile, dst=0)
         else:
             ds.render_tiles_begin(cam, cfg, W, H, spp, W, H, 0, 1, bufs[slot].data_ptr(), s.cuda_stream, slot)
             frames[slot] = bufs[slot].view(H, W, 3)
@@ -177,9 +177,10 @@ def main():
     def end(slot):
         """Waits for the slot's frame; returns its stats."""
         st = ds.render_tiles_end(slot)
-        if st["frame_attempts"] > 1 and world > 1:  # the frame was redone after the gather had been enqueued
-            with torch.cuda.stream(streams[slot]):
-                frames[slot] = D.gather_frame(bufs[slot], W, H, tile, tile)
+        if st["frame_attempts"] > 1 and world > 1:
+            # the frame was redone after its gather had been enqueued, on this rank only: the sizing
+            # frame below exists so that this cannot happen once the collectives have started
+            raise RuntimeError("a ray queue overflowed during the run; raise MIRT_RAY_QUEUE / MIRT_SHADOW_QUEUE")
         return st
 
     def run(n, depth=depth):
@@ -201,6 +202,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # sizing frame, no collective: allocates the working memory and, should a queue overflow, finds
+    # the finer launch split this frame shape needs (the scene handle remembers it) on every rank by itself
+    for slot in range(depth):
+        if world > 1:
+            ds.render_tiles_begin(cam, cfg, W, H, spp, tile, tile, rank, world, bufs[slot].data_ptr(),
+                                  streams[slot].cuda_stream, slot)
+        else:
+            ds.render_tiles_begin(cam, cfg, W, H, spp, W, H, 0, 1, bufs[slot].data_ptr(), streams[slot].cuda_stream, slot)
+        ds.render_tiles_end(slot)
     if args.warmup:
         run(args.warmup)
     barrier()

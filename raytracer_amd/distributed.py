@@ -33,18 +33,28 @@ def assemble(gathered, width, height, tile_w, tile_h, world):
     return g.reshape(tiles_y * tile_h, tiles_x * tile_w, 3)[:height, :width]
 
 
-def gather_frame(local, width, height, tile_w, tile_h, group=None):
-    """All-gathers the ranks' tile buffers and returns the assembled frame (on every rank)."""
+def gather_frame(local, width, height, tile_w, tile_h, group=None, dst=None):
+    """Gathers the ranks' tile buffers and returns the assembled frame.
+    dst=None: all-gather, the frame on every rank.  dst=r: gather to rank r only (the rank that writes
+    the image), None elsewhere -- every other rank sends its buffer over its own xGMI link to r at
+    the same time instead of passing everybody's around a ring."""
     world = dist.get_world_size(group)
-    out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local, group=group)
-    return assemble(out, width, height, tile_w, tile_h, world)
+    if dst is None:
+        out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return assemble(out, width, height, tile_w, tile_h, world)
+    if dist.get_rank(group) == dst:
+        out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        dist.gather(local, list(out.view(world, -1).unbind(0)), dst=dst, group=group)
+        return assemble(out, width, height, tile_w, tile_h, world)
+    dist.gather(local, None, dst=dst, group=group)
+    return None
 
 
-def render_frame(scene, camera, config, width, height, spp, local, tile=TILE, group=None):
-    """Renders this rank's tiles into `local` (a CUDA tensor from local_buffer) and gathers the frame.
-    Returns (frame, stats of this rank)."""
+def render_frame(scene, camera, config, width, height, spp, local, tile=TILE, group=None, dst=None):
+    """Renders this rank's tiles into `local` (a CUDA tensor from local_buffer) and gathers the frame
+    (see gather_frame for dst).  Returns (frame, stats of this rank)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     stream = torch.cuda.current_stream(local.device).cuda_stream
     stats = scene.render_tiles(camera, config, width, height, spp, tile, tile, rank, world, local.data_ptr(), stream)
-    return gather_frame(local, width, height, tile, tile, group), stats
+    return gather_frame(local, width, height, tile, tile, group, dst), stats

@@ -60,6 +60,10 @@ def _worker(rank, world, port, width, height, tile, result_dir):
         mine = synthetic_tiles(width, height, tile, tile, rank, world).reshape(-1)
         local[: mine.size] = torch.from_numpy(mine)
         frame = D.gather_frame(local, width, height, tile, tile)
+        at_root = D.gather_frame(local, width, height, tile, tile, dst=0)  # what bench.py does
+        assert (at_root is None) == (rank != 0)
+        if rank == 0:
+            assert torch.equal(at_root, frame)
         # the bench's max-over-ranks timing reduction
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
