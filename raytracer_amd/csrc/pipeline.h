@@ -1,26 +1,28 @@
 // The render pipeline kernels (gfx950, 64-lane waves):
 //
 //   k_trace<PRIMARY>   one lane per ray: generate it (PRIMARY) or read it from the depth's ray queue,
-//                      find the closest hit by the wave-coherent BVH walk below, shade it without
+//                      find the closest hit by one of the BVH walks below, shade it without
 //                      visibility (ambient, emission, per-light Blinn-Phong terms), append one shadow
 //                      work item per contributing light and the reflection / glossy / refraction rays
-//                      to the next depth's queue (wave ballot + one atomic per wave and queue).
+//                      to the next depth's queue (wave ballot + one atomic per wave on a sharded tail).
 //   k_shadow           one lane per (hit, light): walks the strata of the light, each as a chain of
 //                      closest-hit segments through transparent objects, then adds the light's
 //                      contribution times its visibility to the pixel.
-//   k_resolve          mean over samples, tone map, gamma.
-//   k_trace_ids        parity hook: closest hit of pixel-centre rays.
+//   k_resolve          mean over samples, tone map, gamma; leaves the accumulator zeroed.
+//   k_trace_ids, k_trace_rays   parity hooks: closest hit of pixel-centre rays / of given rays.
 //
 // The ray tree of the reference's recursive trace() (Code/Render/Raytracer.cpp:296-473) is linear in
 // the colours its children return, so every ray carries the RGB weight with which its radiance
-// enters the pixel and the tree is processed one depth at a time.
+// enters the pixel and the tree is processed one depth at a time.  Launches that consume a queue
+// read its length from the producer's tail counters on the device; the host never waits inside a frame.
 //
-// BVH walk: nodes are stored in the reference's own visiting order with skip links, so the walk
-// needs no stack, and it is driven per WAVE: the node index is wave-uniform, node and primitive
-// records are fetched once per wave through the scalar data path, and every lane tests its own ray
-// against them (lanes whose ray missed a box sleep until the walk leaves that subtree).  Primitive
-// kind and transform kind are therefore uniform branches: the six intersectors never diverge
-// against each other inside a wave.
+// BVH walks: nodes are stored in the reference's own visiting order with skip links, so the
+// reference's walk needs no stack.  traverse_packet drives it per WAVE: the node index is
+// wave-uniform, node and primitive records are fetched once per wave through the scalar data path,
+// and every lane tests its own ray against them (lanes whose ray missed a box sleep until the walk
+// leaves that subtree); primitive kind and transform kind are then uniform branches, so the six
+// intersectors never diverge against each other inside a wave.  traverse_lane walks per lane in the
+// same order (large scenes); traverse_ordered walks per lane, nearer child first (opt-in).
 #pragma once
 
 #include "geometry.h"
