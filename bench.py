@@ -279,7 +279,10 @@ def main():
                          "bytes_per_ray": b_ray, "node_tests_per_ray": nn / max(q, 1),
                          "prim_tests_per_ray": npr / max(q, 1), "rays_per_launch": q / max(launches, 1),
                          "avg_launch_ms": avg_ms,
-                         "timed_on": f"{n_timed} frame(s) rendered one at a time after the timed region"},
+                         "timed_on": f"{n_timed} frame(s) rendered one at a time after the timed region",
+                         "note": "algorithmic bytes charge every node and primitive test as memory traffic; a scene "
+                                 "that stays in the scalar cache / L2 can therefore exceed the HBM peak -- traffic "
+                                 "is the measured HBM bytes per launch"},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline(args.scene, W // 2, H // 2, spp, args.max_depth, line["rays_per_sample"])
