@@ -30,14 +30,21 @@
 
 #define WAVE 64
 
-// Register budget of the two big kernels, as waves per SIMD the compiler must make room for.
+// Register budget of the two big kernels, as waves per SIMD the compiler must make room for.  The
+// packet walk is bound by fp64 issue: three waves without (much) spilling beat four with.  The
+// per-lane walks wait on dependent node fetches most of the time: there a fourth wave is worth more
+// than the registers it takes away (measured 12 % on a million primitives).
 #ifndef MIRT_TRACE_WAVES
 #define MIRT_TRACE_WAVES 3
 #endif
 #ifndef MIRT_SHADOW_WAVES
 #define MIRT_SHADOW_WAVES 3
 #endif
+#ifndef MIRT_LANE_WALK_WAVES
+#define MIRT_LANE_WALK_WAVES 4
+#endif
 #define WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#define WAVES_FOR_WALK(walk, packet_waves) WAVES_PER_SIMD((walk) == WALK_PACKET ? (packet_waves) : MIRT_LANE_WALK_WAVES)
 // Keeps the compiler from carrying values in registers across a section whose register budget is
 // tight: what is stored to LDS before the fence has to be loaded again after the next one.
 #define PARK_FENCE() asm volatile("" ::: "memory")
@@ -134,28 +141,45 @@ DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double 
 // records are fetched per lane; the branches on primitive and transform kind diverge, so a wave
 // pays for every kind some lane holds.  The sequence of tests of each ray is the same as in the
 // packet walk, and so is the result.
+#ifndef LANE_FEW_WALKERS
+#define LANE_FEW_WALKERS 24  // stop walking for now when at most this many lanes still walk ...
+#endif
+#ifndef LANE_MANY_PENDING
+#define LANE_MANY_PENDING 8  // ... and at least this many hold a leaf to intersect
+#endif
 template <bool SHADOW, bool UV, bool MOTION>
 DEV void traverse_lane(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
                        Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
   const int n_nodes = sc.n_nodes;
   int node = active ? 0 : n_nodes;
-  while (__any(node < n_nodes)) {
-    int first = 0, count = 0;
-    while (node < n_nodes && count == 0) {
-      const RO DNode &nd = rdonly(sc.nodes)[node];
-      n_node++;
-      if (box_hit(nd, ray, t_min, closest_t)) {
-        if (nd.first >= 0) {
-          first = nd.first;
-          count = nd.count;
-          node = nd.skip;
+  int first = 0, count = 0;  // the leaf this lane holds, to be intersected at the next drain
+  while (__any(node < n_nodes || count > 0)) {
+    // Walk: lanes without a leaf follow their skip links.  The phase ends when nobody walks any more,
+    // or early when only a few stragglers do while many lanes wait with a leaf: a walking step
+    // costs the wave the same with 2 lanes as with 60, and the stragglers simply go on next round
+    // (a lane's own sequence of tests does not depend on when it waits).
+    for (;;) {
+      const bool walking = node < n_nodes && count == 0;
+      const int n_walking = __popcll(__ballot(walking));
+      if (n_walking == 0) break;
+      if (n_walking <= LANE_FEW_WALKERS && __popcll(__ballot(count > 0)) >= LANE_MANY_PENDING) break;
+      if (walking) {
+        const RO DNode &nd = rdonly(sc.nodes)[node];
+        n_node++;
+        if (box_hit(nd, ray, t_min, closest_t)) {
+          if (nd.first >= 0) {
+            first = nd.first;
+            count = nd.count;
+            node = nd.skip;
+          } else {
+            node = node + 1;
+          }
         } else {
-          node = node + 1;
+          node = nd.skip;
         }
-      } else {
-        node = nd.skip;
       }
     }
+    // Drain: every lane that holds a leaf intersects its primitives, in leaf order.
     for (int k = 0; __any(k < count); k++) {
       if (k < count) {
         const int pi = rdonly(sc.leaf_prims)[first + k];
@@ -163,6 +187,7 @@ DEV void traverse_lane(const DScene &sc, const RayL &ray, bool active, double t_
         isect_prim<SHADOW, UV, MOTION>(sc, rdonly(sc.prims)[pi], pi, ray, t_min, closest_t, best);
       }
     }
+    count = 0;
   }
 }
 
@@ -693,7 +718,7 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 // PRIMARY: one grid block per (pixel block, sample).  Otherwise the grid has a fixed size and its
 // blocks stride over the virtual blocks of the input queue, whose length only the device knows.
 template <bool PRIMARY, bool UV, bool MOTION, int WALK>
-__global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
+__global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
   unsigned n_node = 0, n_prim = 0;
   if (PRIMARY) {
     trace_block<true, UV, MOTION, WALK>(a, blockIdx.x, true, 0, n_node, n_prim);
@@ -847,7 +872,7 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
 
 // Fixed-size grid striding over the virtual blocks of the shadow queue.
 template <int WALK>
-__global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
+__global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
   const WaveView v = wave_view(a.count, a.shard_cap);
   for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
