@@ -129,6 +129,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 control flow on a one-GPU box: all ranks render on GPU 0 and the gather
+    # goes through host memory with gloo (RCCL refuses two ranks on one device).  Not a measurement.
+    rehearsal = bool(os.environ.get("MIRT_BENCH_ONE_GPU"))
+    if rehearsal:
+        local_rank = 0
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU path")
     if world != args.gpus:
@@ -137,7 +142,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if args.scene.startswith("synthetic:"):
         hs = HostScene.synthetic(int(args.scene.split(":")[1]))
@@ -169,7 +177,8 @@ def main():
         if world > 1:
             ds.render_tiles_begin(cam, cfg, W, H, spp, tile, tile, rank, world, bufs[slot].data_ptr(), s.cuda_stream, slot)
             with torch.cuda.stream(s):
-                frames[slot] = D.gather_frame(bufs[slot], W, H, tile, tile, dst=0)
+                src = bufs[slot].cpu() if rehearsal else bufs[slot]
+                frames[slot] = D.gather_frame(src, W, H, tile, tile, dst=0)
         else:
             ds.render_tiles_begin(cam, cfg, W, H, spp, W, H, 0, 1, bufs[slot].data_ptr(), s.cuda_stream, slot)
             frames[slot] = bufs[slot].view(H, W, 3)
@@ -227,9 +236,10 @@ def main():
 
     keys = ["primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
             "shadow_prim_tests", "trace_kernel_launches", "shadow_kernel_launches"]
+    red_dev = "cpu" if rehearsal else device
     tot = torch.tensor([float(acc[k]) for k in keys] + [acc["trace_kernel_ms"], acc["shadow_kernel_ms"]],
-                       dtype=torch.float64, device=device)
-    tmax = torch.tensor([elapsed, acc["trace_kernel_ms"], acc["shadow_kernel_ms"]], dtype=torch.float64, device=device)
+                       dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([elapsed, acc["trace_kernel_ms"], acc["shadow_kernel_ms"]], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -268,7 +278,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not (world > 1 and rehearsal) else "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)",
             "config": {"workload": workload, "preset": args.config, "tile": tile if world > 1 else None,
                        "parallelism": f"tiles/{world}", "frames_in_flight": depth},
             "mrays_all_per_s": rays_all / elapsed / 1e6,
