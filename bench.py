@@ -170,6 +170,18 @@ def main():
         bufs = [torch.empty(W * H * 3, dtype=torch.float64, device=device) for _ in range(depth)]
     streams = [torch.cuda.Stream(device) for _ in range(depth)]
     frames = [None] * depth
+    gather_to = [0]  # rank that receives the frame; None: all-gather (fallback if the backend lacks gather)
+
+    def gather(src):
+        try:
+            return D.gather_frame(src, W, H, tile, tile, dst=gather_to[0])
+        except (RuntimeError, NotImplementedError) as e:
+            if gather_to[0] is None:
+                raise
+            if rank == 0:
+                print(f"bench: gather to rank 0 failed ({e}); using all-gather", file=sys.stderr)
+            gather_to[0] = None  # every rank fails the same way on an unsupported collective
+            return D.gather_frame(src, W, H, tile, tile, dst=None)
 
     def begin(slot):
         """Enqueues one frame (this rank's tiles, then the gather) on the slot's stream."""
@@ -177,8 +189,7 @@ def main():
         if world > 1:
             ds.render_tiles_begin(cam, cfg, W, H, spp, tile, tile, rank, world, bufs[slot].data_ptr(), s.cuda_stream, slot)
             with torch.cuda.stream(s):
-                src = bufs[slot].cpu() if rehearsal else bufs[slot]
-                frames[slot] = D.gather_frame(src, W, H, tile, tile, dst=0)
+                frames[slot] = gather(bufs[slot].cpu() if rehearsal else bufs[slot])
         else:
             ds.render_tiles_begin(cam, cfg, W, H, spp, W, H, 0, 1, bufs[slot].data_ptr(), s.cuda_stream, slot)
             frames[slot] = bufs[slot].view(H, W, 3)
