@@ -1,5 +1,5 @@
 // Command line of the drop-in renderer: the flags, defaults and exit codes of the reference's
-// `raytracer` binary (Code/Core/Main.cpp:19-207), plus --seed and --device for the engine.
+// `raytracer` binary (Code/Core/Main.cpp:19-207), plus --seed, --device and --binary-ppm for the engine.
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -32,6 +32,7 @@ void print_help(const char *prog) {
             << "  --log-level <level>      Set log level (debug, info, warn, error)\n"
             << "  --seed <n>               Seed of the sampling sequence (default: 0)\n"
             << "  --device <n>             HIP device to render on (default: 0)\n"
+            << "  --binary-ppm             Write the image as binary PPM (P6) instead of ASCII (P3)\n"
             << "  --help                   Display this help message\n";
 }
 
@@ -74,6 +75,7 @@ void parse_arguments(int argc, char *argv[]) {
     else if (a == "--log-level" && left >= 1) g_config.log_level = argv[++i];
     else if (a == "--seed" && left >= 1) g_config.seed = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "--device" && left >= 1) g_config.device = std::atoi(argv[++i]);
+    else if (a == "--binary-ppm") g_config.output_format = "p6";
     else {
       host_log(LogLevel::Error, "Unknown argument arg=%s", a.c_str());
       print_help(argv[0]);
@@ -131,6 +133,7 @@ int main(int argc, char *argv[]) {
   try {
     Image out =
         render_scene_bvh_antialiased(scene, cam, width, height, g_config.aa_samples, g_config.shadow_samples);
+    if (g_config.output_format == "p6") out.magic_number = "P6";  // a 4K frame is 25 MB instead of ~90 MB of text
     out.write(g_config.output_file);
   } catch (const std::exception &e) {
     host_log(LogLevel::Fatal, "%s", e.what());
