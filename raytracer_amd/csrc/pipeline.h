@@ -393,29 +393,24 @@ DEV void pixel_add(double *accum, uint32_t pixel, d3 c) {
   unsafeAtomicAdd(p + 2, c.z);
 }
 
-// Appends one ray per pushing lane to the block's shard of the queue: the wave counts its pushers
-// with a ballot, one lane reserves the range with a single atomic on the shard's tail, every pusher
-// writes at base + its rank among the pushers.
-DEV void queue_push(const DRayQueue &q, uint32_t *count, uint32_t shard, bool push, d3 o, d3 d, double time, d3 w,
-                    uint64_t key, uint32_t pixel) {
-  const unsigned long long mask = __ballot(push);
-  if (mask == 0) return;
-  const int lane = __lane_id();
-  const int leader = __ffsll((long long)mask) - 1;
+// Appending to the block's shard of a ray queue: the wave counts what it is going to append, one lane
+// reserves the range with a single atomic on the shard's tail (queue_reserve), and every pushing
+// lane writes at the range's start + its rank among the pushers (queue_write).
+DEV uint32_t queue_reserve(uint32_t *count, uint32_t shard, uint32_t n) {
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(count + shard * QUEUE_COUNT_STRIDE, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  if (push) {
-    const uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (r < q.shard_cap) {  // a full shard drops the ray; the host sees the tail past the capacity and redoes the frame
-      const size_t i = (size_t)shard * q.shard_cap + r;
-      q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
-      q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
-      q.time[i] = time;
-      q.wr[i] = w.x; q.wg[i] = w.y; q.wb[i] = w.z;
-      q.key[i] = key;
-      q.pixel[i] = pixel;
-    }
+  if (__lane_id() == 0) base = atomicAdd(count + shard * QUEUE_COUNT_STRIDE, n);
+  return __shfl(base, 0);
+}
+DEV void queue_write(const DRayQueue &q, uint32_t shard, uint32_t r, d3 o, d3 d, double time, d3 w, uint64_t key,
+                     uint32_t pixel) {
+  if (r < q.shard_cap) {  // a full shard drops the ray; the host sees the tail past the capacity and redoes the frame
+    const size_t i = (size_t)shard * q.shard_cap + r;
+    q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
+    q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
+    q.time[i] = time;
+    q.wr[i] = w.x; q.wg[i] = w.y; q.wb[i] = w.z;
+    q.key[i] = key;
+    q.pixel[i] = pixel;
   }
 }
 
@@ -665,27 +660,41 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 #endif
   if (!spawn) return;  // wave-uniform
 
-  // ---- reflection (Raytracer.cpp:317-411); dropped when the glass branch returns `combined` ----
-  {
-    const bool refl = hit && R > 0.0 && !pass;
+  // ---- children: reflection (Raytracer.cpp:317-411; dropped when the glass branch returns `combined`),
+  // Fresnel reflection and refraction (Raytracer.cpp:414-464).  The wave first counts all the rays it
+  // is going to append, reserves room for them with one atomic, then writes them kind by kind.
+  const bool refl = hit && R > 0.0 && !pass;
+  int samples = 1;
+  if (cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
+  const bool mirror = samples == 1 || m.glossiness > 0.94;
+  const bool push_mirror = refl && mirror, lobe = refl && !mirror;  // a lobe lane appends glossy_samples rays
+  const bool push_reflect = hit && glass, push_refract = hit && glass && !tir;
+  const unsigned long long m_mirror = __ballot(push_mirror), m_lobe = __ballot(lobe), m_reflect = __ballot(push_reflect),
+                           m_refract = __ballot(push_refract);
+  const uint32_t n_mirror = (uint32_t)__popcll(m_mirror), n_lobe = (uint32_t)__popcll(m_lobe),
+                 n_reflect = (uint32_t)__popcll(m_reflect), n_refract = (uint32_t)__popcll(m_refract);
+  const uint32_t n_samples = (uint32_t)cfg.glossy_samples;
+  const uint32_t total = n_mirror + n_lobe * n_samples + n_reflect + n_refract;
+  if (total) {
+    const unsigned long long below = (1ull << __lane_id()) - 1ull;
+    uint32_t at = queue_reserve(a.out_count, shard, total);
     const d3 r = reflect_dir(ray.d, sn);
-    int samples = 1;
-    if (cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
-    const bool mirror = samples == 1 || m.glossiness > 0.94;
     const bool metal = R > 0.5 && T < 0.1;
     d3 cw = ws * R;
     if (metal) cw = cw * tint;
     const d3 org = sf.p + sf.n * eps;
-    queue_push(a.out, a.out_count, shard, refl && mirror, org, r, time, cw, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY), pixel);
-    const bool lobe = refl && !mirror;
-    if (__any(lobe)) {
+    if (push_mirror)
+      queue_write(a.out, shard, at + (uint32_t)__popcll(m_mirror & below), org, r, time, cw,
+                  mirt_rng_child_key(key, MIRT_SLOT_GLOSSY), pixel);
+    at += n_mirror;
+    if (m_lobe) {
       const d3 w = r;
       const d3 u = unit(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
       const d3 v = cross(w, u);
       const double expo = pow(10.0, m.glossiness * 4.0);
       const d3 cws = cw / (double)samples;
-      for (int i = 0; i < cfg.glossy_samples; i++) {
-        const bool on = lobe && i < samples;
+      const uint32_t rank = (uint32_t)__popcll(m_lobe & below);
+      for (uint32_t i = 0; i < n_samples; i++) {
         const double r1 = mirt_rng_draw(key, MIRT_DIM_GLOSSY + 2u * i);
         const double r2 = mirt_rng_draw(key, MIRT_DIM_GLOSSY + 2u * i + 1);
         const double ct = pow(r1, 1.0 / (expo + 1.0));
@@ -694,20 +703,19 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
         sincos(2.0 * M_PI * r2, &sp, &cp);
         d3 dir = unit(u * (st * cp) + v * (st * sp) + w * ct);
         if (dot(dir, sf.n) < 0) dir = r;
-        queue_push(a.out, a.out_count, shard, on, org, dir, time, cws, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY + i), pixel);
+        if (lobe) queue_write(a.out, shard, at + rank, org, dir, time, cws, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY + i), pixel);
+        at += n_lobe;
       }
     }
-  }
-  // ---- Fresnel reflection and refraction (Raytracer.cpp:414-464) --------------------------------
-  {
-    const bool g = hit && glass;
     const d3 wbase = pass ? W : W * T;
-    const d3 wr = tir ? wbase : wbase * fres;
-    queue_push(a.out, a.out_count, shard, g, sf.p + sf.n * eps, reflect_dir(ray.d, sf.n), time, wr,
-               mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFLECT), pixel);
-    const d3 para = sf.n * (-sqrt(maxd(0.0, disc)));
-    queue_push(a.out, a.out_count, shard, g && !tir, sf.p - sf.n * eps, perp + para, time, wbase * (1.0 - fres),
-               mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFRACT), pixel);
+    if (push_reflect)
+      queue_write(a.out, shard, at + (uint32_t)__popcll(m_reflect & below), sf.p + sf.n * eps, reflect_dir(ray.d, sf.n), time,
+                  tir ? wbase : wbase * fres, mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFLECT), pixel);
+    at += n_reflect;
+    if (push_refract)
+      queue_write(a.out, shard, at + (uint32_t)__popcll(m_refract & below), sf.p - sf.n * eps,
+                  perp + sf.n * (-sqrt(maxd(0.0, disc))), time, wbase * (1.0 - fres),
+                  mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFRACT), pixel);
   }
 #if MIRT_PROFILE == 1
   PROF_MARK(4);
