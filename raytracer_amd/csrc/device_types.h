@@ -115,6 +115,8 @@ struct DLightFrame {
   uint32_t dim;   // first random dimension of this light's strata (mirt_rng.h, MIRT_DIM_SHADOW)
   int32_t side;   // floor(sqrt(samples)), at least 1; side*side strata are taken
   double inv_n;   // 1 / (side*side)
+  // area lights: the basis Light::sample_point (Light.h:44-52) builds on every call, built once
+  double right[3], up[3];
 };
 
 // Ray queue, structure of arrays; one queue per ray-tree depth.

@@ -617,6 +617,24 @@ MIRT_API int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int 
 
 namespace {
 
+// The orthonormal basis around an area light's normal (Light.h:44-52), same expressions in the same
+// order as the reference evaluates per sample.
+void device_light_basis(const mirt_light &L, DLightFrame &lf) {
+  auto unit = [](Vec3 a) {
+    const double len = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return Vec3(a.x / len, a.y / len, a.z / len);
+  };
+  auto cross = [](Vec3 a, Vec3 b) { return Vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); };
+  Vec3 n(L.normal[0], L.normal[1], L.normal[2]);
+  if (n.x * n.x + n.y * n.y + n.z * n.z < 0.1) n = Vec3(0, 0, -1);
+  n = unit(n);
+  Vec3 right = std::fabs(n.x) > 0.9 ? Vec3(0, 1, 0) : Vec3(1, 0, 0);
+  right = unit(cross(n, right));
+  const Vec3 up = unit(cross(n, right));
+  lf.right[0] = right.x; lf.right[1] = right.y; lf.right[2] = right.z;
+  lf.up[0] = up.x; lf.up[1] = up.y; lf.up[2] = up.z;
+}
+
 // Geometry of one rank's share of a frame.
 struct FrameShape {
   DFrame fr;
@@ -676,6 +694,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       lf[l].dim = dim;
       lf[l].side = side;
       lf[l].inv_n = 1.0 / (side * side);
+      device_light_basis(L, lf[l]);
       dim += 2u * (uint32_t)(side * side);
     }
     // blocking copy from pageable memory: done once per shadow_samples value, not per frame; frames

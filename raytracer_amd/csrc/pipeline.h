@@ -369,15 +369,11 @@ DEV void camera_ray(const DCamera &c, double x, double y, int width, int height,
   }
 }
 
-// Light::sample_point (Light.h:38-69)
-template <class L> DEV d3 light_point(const L &l, double u, double v) {
+// Light::sample_point (Light.h:38-69); the basis around the light's normal comes from DLightFrame
+// (device_light_basis in engine.cpp evaluates the same expressions once per light).
+template <class L> DEV d3 light_point(const L &l, const DLightFrame &lf, double u, double v) {
   if (l.type != MIRT_LIGHT_AREA) return ld3(l.location);
-  d3 n = ld3(l.normal);
-  if (len2(n) < 0.1) n = mk(0, 0, -1);
-  n = unit(n);
-  d3 right = fabs(n.x) > 0.9 ? mk(0, 1, 0) : mk(1, 0, 0);
-  right = unit(cross(n, right));
-  const d3 up = unit(cross(n, right));
+  const d3 right = ld3(lf.right), up = ld3(lf.up);
   if (l.area_shape == MIRT_AREA_RECT)
     return ld3(l.location) + right * ((u - 0.5) * l.area_size[0]) + up * ((v - 0.5) * l.area_size[1]);
   const double r = sqrt(u);
@@ -805,7 +801,7 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
       const uint32_t dim = dim0 + 2u * (uint32_t)s;
       const double u = (si + mirt_rng_draw(key, dim)) / side;
       const double v = (sj + mirt_rng_draw(key, dim + 1)) / side;
-      const d3 to = light_point(L, u, v) - P;
+      const d3 to = light_point(L, a.fr.light_frame[park_light[tid]], u, v) - P;
       dist = len(to);
       dir = to / dist;
       att = 1.0;
