@@ -61,3 +61,30 @@ def test_keyed_and_sequential_agree_without_randomness(host_scenes):
     a, _ = O.render(hs.desc, cam, cfg, 48, 27, 1, O.RNG_SEQUENTIAL)
     b, _ = O.render(hs.desc, cam, cfg, 48, 27, 1, O.RNG_KEYED)
     assert np.array_equal(a, b)
+
+
+def test_addressed_draws_give_the_reference_programs_image(host_scenes, tmp_path):
+    """The oracle with ADDRESSED draws (the mode the GPU is compared with) against a frame of the
+    reference program itself at the same sample count: two independent Monte-Carlo estimates, so the
+    bound is statistical (mean absolute error of the 8-bit image <= 0.01 of full scale at 64 spp)."""
+    import subprocess
+
+    from conftest import FIXTURES, ROOT
+    from raytracer_amd import read_ppm
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "raytracer_ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/raytracer_ref not built")
+    w, h, spp = 160, 90, 64
+    os.symlink(os.path.join(FIXTURES, "ASCII"), tmp_path / "ASCII")
+    os.symlink(os.path.join(FIXTURES, "Textures"), tmp_path / "Textures")
+    out = tmp_path / "ref.ppm"
+    subprocess.run([ref_bin, "--scene", "ASCII/Test5.txt", "--resolution", str(w), str(h), "--samples", str(spp),
+                    "--max-depth", "5", "--output", str(out)], cwd=tmp_path, check=True, capture_output=True, timeout=300)
+    ref, _ = read_ppm(str(out))
+    hs = host_scenes("Test5")
+    cam, _ = hs.camera(0)
+    got, _ = O.render(hs.desc, cam, default_config(max_ray_depth=5), w, h, spp, O.RNG_KEYED)
+    got8 = np.floor(np.clip(got, 0.0, 1.0) * 255.0 + 0.5) / 255.0
+    mae = float(np.abs(got8 - ref.reshape(h, w, 3)).mean())
+    print(f"oracle (addressed draws) vs reference program: MAE {mae:.5f}")
+    assert mae <= 0.01
