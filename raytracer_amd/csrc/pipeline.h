@@ -558,8 +558,8 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 
   // ---- shading of the hit (Raytracer.cpp:305-466), visibility deferred to k_shadow ------------
   const bool spawn = a.depth + 1 < cfg.max_ray_depth;  // deeper rays would return black (Raytracer.cpp:297)
-  const int pidx = hit ? best.prim : 0;
-  const mirt_material &m = sc.materials[sc.prims[pidx].material];
+  // lanes without a hit bind `m` to material 0 and never read it (a scene may have no primitives at all)
+  const mirt_material &m = sc.materials[hit ? sc.prims[best.prim].material : 0];
   Surface<UV> sf = {};
   d3 sn = mk(0, 0, 1), tint = mk(0, 0, 0), amb = mk(0, 0, 0);
   double R = 0, T = 0, eps = 0;
@@ -660,9 +660,10 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
   // Fresnel reflection and refraction (Raytracer.cpp:414-464).  The wave first counts all the rays it
   // is going to append, reserves room for them with one atomic, then writes them kind by kind.
   const bool refl = hit && R > 0.0 && !pass;
+  // a lane without a hit has no material: `m` is only read behind `refl`
   int samples = 1;
-  if (cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
-  const bool mirror = samples == 1 || m.glossiness > 0.94;
+  if (refl && cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
+  const bool mirror = samples == 1 || (refl && m.glossiness > 0.94);
   const bool push_mirror = refl && mirror, lobe = refl && !mirror;  // a lobe lane appends glossy_samples rays
   const bool push_reflect = hit && glass, push_refract = hit && glass && !tir;
   const unsigned long long m_mirror = __ballot(push_mirror), m_lobe = __ballot(lobe), m_reflect = __ballot(push_reflect),
@@ -687,7 +688,7 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
       const d3 w = r;
       const d3 u = unit(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
       const d3 v = cross(w, u);
-      const double expo = pow(10.0, m.glossiness * 4.0);
+      const double expo = pow(10.0, (lobe ? m.glossiness : 0.0) * 4.0);
       const d3 cws = cw / (double)samples;
       const uint32_t rank = (uint32_t)__popcll(m_lobe & below);
       for (uint32_t i = 0; i < n_samples; i++) {

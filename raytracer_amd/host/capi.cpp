@@ -3,6 +3,7 @@
 // load_scene + flatten_scene and the PPM writer; none of them touches the GPU.
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 
@@ -59,25 +60,49 @@ template <class S> void dump_placed(std::FILE *f, const S &s, const Vec3 &loc) {
 }
 }  // namespace
 
+namespace {
+thread_local std::string g_host_error;
+
+// Runs `fill` on a fresh HostScene; no C++ exception leaves the library (the loader throws
+// std::runtime_error on a truncated matrix block, as the reference does: SceneLoader.cpp:400).
+template <class F> void *make_scene(F fill) {
+  HostScene *h = nullptr;
+  try {
+    h = new HostScene;
+    fill(*h);
+    g_host_error.clear();
+    return h;
+  } catch (const std::exception &e) {
+    g_host_error = e.what();
+  } catch (...) {
+    g_host_error = "unknown C++ exception";
+  }
+  delete h;
+  return nullptr;
+}
+}  // namespace
+
 extern "C" {
 
+// Message of the last mirt_host_scene_load / mirt_host_scene_synthetic that returned NULL on this thread.
+const char *mirt_host_last_error(void) { return g_host_error.c_str(); }
+
 // Parses `path` and flattens it.  texture_root: directory holding Textures/ ("" = CWD).
-// Returns NULL only when out of memory; a missing file yields an empty scene, as load_scene does.
+// A missing file yields an empty scene, as load_scene does; NULL means the parser threw or memory
+// ran out (mirt_host_last_error() says which).
 void *mirt_host_scene_load(const char *path, const char *texture_root) {
-  HostScene *h = new (std::nothrow) HostScene;
-  if (!h) return nullptr;
-  h->scene = load_scene(path ? path : "");
-  h->flat = flatten_scene(h->scene, texture_root ? texture_root : "");
-  return h;
+  return make_scene([&](HostScene &h) {
+    h.scene = load_scene(path ? path : "");
+    h.flat = flatten_scene(h.scene, texture_root ? texture_root : "");
+  });
 }
 
 // The synthetic cloud of make_synthetic_scene(n_prims, seed), flattened.
 void *mirt_host_scene_synthetic(int n_prims, uint64_t seed) {
-  HostScene *h = new (std::nothrow) HostScene;
-  if (!h) return nullptr;
-  h->scene = make_synthetic_scene(n_prims, seed);
-  h->flat = flatten_scene(h->scene, "");
-  return h;
+  return make_scene([&](HostScene &h) {
+    h.scene = make_synthetic_scene(n_prims, seed);
+    h.flat = flatten_scene(h.scene, "");
+  });
 }
 
 // Writes the handle's scene in the ASCII grammar (sphere / torus / cylinder / cone scenes only).

@@ -244,6 +244,10 @@ def test_edge_cases(host_scenes, device_scenes, tmp_path):
     ce, _ = he.camera(0)
     img, _ = de.render(ce, default_config(enable_gamma_correction=0), 8, 8, 2)
     assert np.allclose(img, np.broadcast_to([0.125, 0.25, 0.5], (8, 8, 3)), atol=1e-15)
+    # ... also with every ray-spawning feature switched on: lanes without a hit read no material
+    img, st = de.render(ce, default_config(enable_gamma_correction=0, glossy_samples=4, max_ray_depth=3), 8, 8, 2)
+    assert np.allclose(img, np.broadcast_to([0.125, 0.25, 0.5], (8, 8, 3)), atol=1e-15)
+    assert st["secondary_rays"] == 0 and st["shadow_segments"] == 0
     # invisible objects stay in the BVH but are never hit (Bvh.cpp:255-278)
     hv = HostScene(scene_path("Test5"), FIXTURES)
     for i in range(hv.desc.n_prims):

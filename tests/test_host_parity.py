@@ -70,16 +70,15 @@ def test_missing_scene_is_empty_not_an_error(tmp_path):
         hs.camera(0)
 
 
-def test_truncated_matrix_block_is_tolerated_at_eof(tmp_path):
+def test_truncated_matrix_block_is_an_error_not_an_abort(tmp_path):
     src = open(scene_path("Test5")).read().split("matrix_t0")[0] + "matrix_t0\n1 0 0 0\n"
     p = tmp_path / "trunc.txt"
     p.write_text(src)
-    # the reference throws std::runtime_error here (SceneLoader.cpp:400); through the C entry point
-    # that would abort the process, so run it in a child
-    code = ("import sys; sys.path.insert(0, %r); from raytracer_amd import HostScene; HostScene(%r, %r)"
-            % (ROOT, str(p), FIXTURES))
-    r = subprocess.run(["python", "-c", code], capture_output=True)
-    assert r.returncode != 0
+    # the reference throws std::runtime_error here (SceneLoader.cpp:400); the C entry point catches
+    # it, returns NULL and keeps the message, and the Python face raises
+    from raytracer_amd import MirtError
+    with pytest.raises(MirtError, match="matrix"):
+        HostScene(str(p), FIXTURES)
 
 
 def test_ppm_writer_matches_reference_format(tmp_path):
