@@ -222,8 +222,10 @@ int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config 
  * mirt_tile_buffer_pixels(...) * 3 doubles: the owned tiles in increasing t, each tile stored
  * row-major as tile_h rows of tile_w pixels (edge tiles are padded; padding is written as 0).
  * With world == 1 and tile_w == width, tile_h == height this is the whole frame, row-major.
- * `stream` is a hipStream_t (NULL: the engine's own stream); the call synchronises it before
- * returning.  No counterpart in the reference (it has one address space). */
+ * `stream` is a hipStream_t; the call synchronises it before returning.  NULL selects the engine's own
+ * (non-blocking) stream, which is first made to wait for the work already enqueued on the null stream,
+ * so that a fill of d_rgb_out issued there beforehand is ordered before the frame.
+ * No counterpart in the reference (it has one address space). */
 int mirt_render_tiles(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
                       int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
                       double *d_rgb_out, void *stream, mirt_stats *stats);
@@ -257,6 +259,24 @@ int mirt_render_tiles_begin(mirt_scene *scene, const mirt_camera *camera, const 
                             int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
                             double *d_rgb_out, void *stream, int slot);
 int mirt_render_tiles_end(mirt_scene *scene, int slot, mirt_stats *stats);
+
+/* mirt_render_tiles for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+ * frame, same statistics -- but the call allocates nothing, on the device or on the host: its working
+ * memory (control block, pixel accumulator, shadow queue, two ray queues) is a carve-up of one static
+ * array of mirt_noalloc_scratch_bytes() = 64 MiB that each GPU the library runs on holds until the
+ * process ends, and its read-back buffer and events are made by mirt_scene_create.  A frame is cut
+ * into as many primary launches as the queues need; a frame that does not fit even so -- the
+ * accumulator (24 bytes per pixel of this rank's tiles) plus the smallest launch (one 16x16 pixel
+ * block, all samples) exceed the array, or more than 255 launch-levels are needed; about a megapixel
+ * at 16 spp -- is refused with MIRT_ERR_UNSUPPORTED and a message that says which limit was hit.
+ * mirt_config.kernel_timing is ignored (per-launch events are created on demand).
+ * All scenes on a GPU share that GPU's array: calls that overlap on one GPU (two threads, two scene
+ * handles) race; calls on different GPUs do not. */
+int mirt_render_tiles_noalloc(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
+                              int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
+                              double *d_rgb_out, void *stream, mirt_stats *stats);
+uint64_t mirt_noalloc_scratch_bytes(void);
 
 /* Engine tuning, no counterpart in the reference: how rays walk the BVH.
  * PACKET (one node index per wave) and LANE (one per ray) test the same boxes and primitives in the

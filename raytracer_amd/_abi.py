@@ -90,7 +90,7 @@ class Stats(C.Structure):
 ENGINE_SYMBOLS = [
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
     "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal", "mirt_render_tiles_begin", "mirt_render_tiles_end",
-    "mirt_last_error", "mirt_abi_version",
+    "mirt_last_error", "mirt_abi_version", "mirt_render_tiles_noalloc", "mirt_noalloc_scratch_bytes",
 ]
 
 
@@ -109,6 +109,8 @@ def _declare_engine(lib):
     lib.mirt_render_tiles_begin.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Config), C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.mirt_render_tiles_end.argtypes = [C.c_void_p, C.c_int, C.POINTER(Stats)]
+    lib.mirt_render_tiles_noalloc.argtypes = lib.mirt_render_tiles.argtypes
+    lib.mirt_noalloc_scratch_bytes.restype = C.c_uint64
     lib.mirt_tile_buffer_pixels.argtypes = [C.c_int] * 6
     lib.mirt_tile_buffer_pixels.restype = C.c_int64
     lib.mirt_trace_ids.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, dp]
@@ -126,6 +128,8 @@ def _declare_host(lib):
     lib.mirt_host_scene_write_ascii.argtypes = [C.c_void_p, C.c_char_p]
     lib.mirt_host_scene_load.restype = C.c_void_p
     lib.mirt_host_scene_load.argtypes = [C.c_char_p, C.c_char_p]
+    lib.mirt_host_last_error.restype = C.c_char_p
+    lib.mirt_host_last_error.argtypes = []
     lib.mirt_host_scene_free.argtypes = [C.c_void_p]
     lib.mirt_host_scene_free.restype = None
     lib.mirt_host_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]

@@ -44,7 +44,7 @@ class HostScene:
         self._lib = lib
         self._h = lib.mirt_host_scene_load(os.fsencode(path), os.fsencode(texture_root))
         if not self._h:
-            raise MemoryError("mirt_host_scene_load")
+            raise MirtError(f"mirt_host_scene_load({path}): {lib.mirt_host_last_error().decode()}")
         self.path = path
         self.desc = A.SceneDesc()
         lib.mirt_host_scene_desc(self._h, C.byref(self.desc))
@@ -57,7 +57,7 @@ class HostScene:
         self._lib = A.host_lib()
         self._h = self._lib.mirt_host_scene_synthetic(int(n_prims), int(seed))
         if not self._h:
-            raise MemoryError("mirt_host_scene_synthetic")
+            raise MirtError(f"mirt_host_scene_synthetic: {self._lib.mirt_host_last_error().decode()}")
         self.path = f"synthetic:{n_prims}:{seed}"
         self.desc = A.SceneDesc()
         self._lib.mirt_host_scene_desc(self._h, C.byref(self.desc))
@@ -151,6 +151,14 @@ class DeviceScene:
         _check(self._lib.mirt_render_tiles(self._h, C.byref(camera), C.byref(config), width, height, spp, tile_w,
                                            tile_h, rank, world, C.c_void_p(out_ptr), C.c_void_p(stream or 0),
                                            C.byref(st)), "mirt_render_tiles")
+        return st.as_dict()
+
+    def render_tiles_noalloc(self, camera, config, width, height, spp, tile_w, tile_h, rank, world, out_ptr, stream=None):
+        """mirt_render_tiles_noalloc: the same frame out of the per-GPU static working memory."""
+        st = A.Stats()
+        _check(self._lib.mirt_render_tiles_noalloc(self._h, C.byref(camera), C.byref(config), width, height, spp,
+                                                   tile_w, tile_h, rank, world, C.c_void_p(out_ptr),
+                                                   C.c_void_p(stream or 0), C.byref(st)), "mirt_render_tiles_noalloc")
         return st.as_dict()
 
     def render_tiles_begin(self, camera, config, width, height, spp, tile_w, tile_h, rank, world, out_ptr, stream,

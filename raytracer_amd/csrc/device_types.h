@@ -221,3 +221,8 @@ void launch_shadow(int walk, unsigned grid, void *stream, const ShadowArgs &a);
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a);
 void launch_trace_ids(int walk, unsigned grid, void *stream, const IdsArgs &a);
 void launch_trace_rays(int walk, unsigned grid, void *stream, const RaysArgs &a);
+
+// Size of the per-GPU static array behind mirt_render_tiles_noalloc (kernels.hip), and the device
+// address of the current device's copy of it (0, or a hipError_t).
+#define MIRT_SCRATCH_BYTES (64u << 20)
+int scratch_address(int device, void **out);

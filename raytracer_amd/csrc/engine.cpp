@@ -46,21 +46,29 @@ int fail(int code, const char *fmt, ...) {
 struct DeviceBuffer {
   void *p = nullptr;
   size_t bytes = 0;
+  bool owned = true;  // false: a window of memory that belongs to somebody else (never freed, never grown)
   DeviceBuffer() = default;
   DeviceBuffer(const DeviceBuffer &) = delete;
   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
-  DeviceBuffer(DeviceBuffer &&o) noexcept : p(o.p), bytes(o.bytes) {
+  DeviceBuffer(DeviceBuffer &&o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) {
     o.p = nullptr;
     o.bytes = 0;
   }
   ~DeviceBuffer() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
   }
+  void borrow(void *mem, size_t n) {
+    release();
+    owned = false;
+    p = mem;
+    bytes = n;
+  }
   hipError_t reserve(size_t n) {  // grow-only
     if (n <= bytes) return hipSuccess;
+    if (!owned) return hipErrorOutOfMemory;
     release();
     hipError_t e = hipMalloc(&p, n);
     if (e == hipSuccess) bytes = n;
@@ -70,8 +78,11 @@ struct DeviceBuffer {
 };
 
 template <class T> hipError_t upload(DeviceBuffer &b, const std::vector<T> &v) {
-  hipError_t e = b.reserve(std::max<size_t>(v.size() * sizeof(T), 16));
-  if (e != hipSuccess || v.empty()) return e;
+  // an empty array still gets one zeroed record: kernels bind references to element 0 before they
+  // know whether a lane has a hit, and a reference may be loaded from ahead of its guard
+  hipError_t e = b.reserve(std::max<size_t>(v.size() * sizeof(T), std::max<size_t>(sizeof(T), 16)));
+  if (e != hipSuccess) return e;
+  if (v.empty()) return hipMemset(b.p, 0, b.bytes);
   return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
@@ -82,6 +93,7 @@ struct RayQueueMem {
   RayQueueMem(RayQueueMem &&o) noexcept : q(o.q) {
     mem.p = o.mem.p;
     mem.bytes = o.mem.bytes;
+    mem.owned = o.mem.owned;
     o.mem.p = nullptr;
     o.mem.bytes = 0;
     o.q = DRayQueue{};
@@ -108,6 +120,7 @@ struct mirt_scene {
   int n_prims = 0;
   int bvh_depth = 0;  // edges from the root to the deepest node
   hipStream_t stream = nullptr;
+  hipEvent_t null_stream_mark = nullptr;  // orders the engine's own stream after the caller's null stream
   DScene d{};
   DeviceBuffer nodes, leaf_prims, prims, motion, materials, transparency, lights, textures, light_frame;
   std::vector<DeviceBuffer> texels;
@@ -116,6 +129,7 @@ struct mirt_scene {
   // Per-frame working memory, grown on demand and kept.  Two sets, so that a second frame can be
   // enqueued (mirt_render_tiles_begin) while the first is still running.
   struct WorkSet {
+    bool fixed = false;  // working memory is a carve-up of the per-GPU static array: nothing is ever allocated
     RayQueueMem queues[2];  // rays of even / odd depth: a depth reads one and appends to the other
     DeviceBuffer shadow_items, control, accum;  // control: statistics counters, then the queue tails
     char *pinned = nullptr;  // read-back of the control block
@@ -139,13 +153,16 @@ struct mirt_scene {
       for (auto e : events) (void)hipEventDestroy(e);
       if (pinned) (void)hipHostFree(pinned);
     }
-  } work[2];
+  } work[2], fixed_work;
+  char *scratch = nullptr;  // device address of this GPU's static array (scratch_address)
+  std::vector<DLightFrame> light_frame_host;
   DeviceBuffer out, ids;
   uint64_t split_for = 0;  // frame shape (primary grid blocks, depth, glossy samples) `split` was found for
   uint32_t split = 1;      // primary launches are cut this many times finer than the queues' sizes suggest
   int light_frame_for = 0;  // shadow_samples the device copy of the lights' strata was made for
   bool light_frame_valid = false;
   ~mirt_scene() {
+    if (null_stream_mark) (void)hipEventDestroy(null_stream_mark);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -353,12 +370,19 @@ int max_children(const SpawnKinds &k, int glossy_samples) {
 }
 
 constexpr size_t kCountBytes = (size_t)QUEUE_SHARDS * QUEUE_COUNT_STRIDE * sizeof(uint32_t);
+// share of the static array set aside for the control block (statistics counters, then 16 KiB of queue
+// tails per primary launch and ray-tree level): 4 MiB = 255 launch-levels
+constexpr size_t kFixedControlBytes = (size_t)4 << 20;
 
-hipError_t ensure_queue(mirt_scene::WorkSet *sc, int which) {
+constexpr size_t kRayBytes = 10 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t);  // one queued ray
+
+// Lays the queue's arrays out over its memory; `at` != NULL: over that memory instead (never allocates).
+hipError_t ensure_queue(mirt_scene::WorkSet *sc, int which, void *at = nullptr) {
   RayQueueMem &rq = sc->queues[which];
   const size_t cap = sc->ray_shard_cap * QUEUE_SHARDS;
-  if (rq.q.shard_cap == sc->ray_shard_cap && rq.mem.p) return hipSuccess;
-  hipError_t e = rq.mem.reserve(cap * (10 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t)));
+  if (at) rq.mem.borrow(at, cap * kRayBytes);
+  else if (rq.q.shard_cap == sc->ray_shard_cap && rq.mem.p) return hipSuccess;
+  hipError_t e = rq.mem.reserve(cap * kRayBytes);
   if (e != hipSuccess) return e;
   char *p = rq.mem.as<char>();
   double **fields[10] = {&rq.q.ox, &rq.q.oy, &rq.q.oz, &rq.q.dx, &rq.q.dy, &rq.q.dz, &rq.q.time, &rq.q.wr, &rq.q.wg, &rq.q.wb};
@@ -375,6 +399,7 @@ hipError_t ensure_queue(mirt_scene::WorkSet *sc, int which) {
 
 hipError_t ensure_pinned(mirt_scene::WorkSet *sc, size_t bytes) {
   if (bytes <= sc->pinned_bytes) return hipSuccess;
+  if (sc->fixed) return hipErrorOutOfMemory;  // sized once, when the scene was created
   if (sc->pinned) (void)hipHostFree(sc->pinned);
   sc->pinned = nullptr;
   sc->pinned_bytes = 0;
@@ -418,6 +443,7 @@ DCamera device_camera(const mirt_camera &c, int width, int height) {
 
 hipError_t get_event(mirt_scene::WorkSet *sc, size_t &used, hipEvent_t &e) {
   if (used == sc->events.size()) {
+    if (sc->fixed) return hipErrorOutOfMemory;  // its two events were created with the scene
     hipEvent_t n;
     hipError_t err = hipEventCreate(&n);
     if (err != hipSuccess) return err;
@@ -513,6 +539,7 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   } guard{sc};
   sc->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&sc->null_stream_mark, hipEventDisableTiming));
 
   const mirt_scene_desc &s = *desc;
   std::vector<DNode> nodes(s.n_nodes);
@@ -584,6 +611,27 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   HIP_TRY(upload(sc->lights, sc->host_lights));
   HIP_TRY(upload(sc->textures, textures));
   HIP_TRY(sc->light_frame.reserve(std::max<size_t>(sizeof(DLightFrame) * s.n_lights, 16)));
+  sc->light_frame_host.resize(s.n_lights);
+
+  // Everything mirt_render_tiles_noalloc will need, so that the call itself allocates nothing: the
+  // address of this GPU's static array, the read-back buffer of the control block and the two
+  // events that bracket a frame.
+  {
+    void *sp = nullptr;
+    const int se = scratch_address(device, &sp);
+    if (se != 0)
+      return fail(MIRT_ERR_DEVICE, "hipGetSymbolAddress(scratch) on device %d: %s", device,
+                  hipGetErrorString(static_cast<hipError_t>(se)));
+    sc->scratch = static_cast<char *>(sp);
+    mirt_scene::WorkSet &fw = sc->fixed_work;
+    HIP_TRY(ensure_pinned(&fw, kFixedControlBytes));
+    for (int k = 0; k < 2; ++k) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      fw.events.push_back(ev);
+    }
+    fw.fixed = true;
+  }
 
   DScene &d = sc->d;
   d.nodes = sc->nodes.as<DNode>();
@@ -683,7 +731,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   // shadow strata per light for this frame (Raytracer.cpp:146-158)
   const int n_lights = sc->d.n_lights;
   if (n_lights && (sc->light_frame_for != config->shadow_samples || !sc->light_frame_valid)) {
-    std::vector<DLightFrame> lf(n_lights);
+    std::vector<DLightFrame> &lf = sc->light_frame_host;  // n_lights entries since the scene was created
     uint32_t dim = MIRT_DIM_SHADOW;
     for (int l = 0; l < n_lights; ++l) {
       const mirt_light &L = sc->host_lights[l];
@@ -721,23 +769,57 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   const uint64_t grid_total = total_blocks * (uint64_t)spp;  // primary grid blocks of the whole frame
   const size_t shard_blocks = (size_t)((grid_total + QUEUE_SHARDS - 1) / QUEUE_SHARDS);
   const size_t min_blocks = std::max<size_t>(1, (size_t)(spp + QUEUE_SHARDS - 1) / QUEUE_SHARDS);  // one pixel block, all samples
-  size_t want_r = env_size("MIRT_RAY_QUEUE", (size_t)32 << 20) / QUEUE_SHARDS;
-  size_t want_s = env_size("MIRT_SHADOW_QUEUE", (size_t)128 << 20) / QUEUE_SHARDS;
-  want_r = std::max(std::min(want_r, shard_blocks * 256 * K), min_blocks * 256 * K);
-  want_s = std::max(std::min(want_s, shard_blocks * 256 * S * std::max(K, 1)), min_blocks * 256 * S);
-  if (want_r * QUEUE_SHARDS > 0xfffffff0u || want_s * QUEUE_SHARDS > 0xfffffff0u)
-    return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
-  if (want_r > ws->ray_shard_cap) ws->ray_shard_cap = want_r;
-  if (want_s > ws->shadow_shard_cap) ws->shadow_shard_cap = want_s;
-  HIP_TRY(ws->shadow_items.reserve(ws->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem)));
-  {
+  const size_t accum_bytes = std::max<size_t>(n_pixels * 3 * sizeof(double), 64);
+  if (!ws->fixed) {
+    size_t want_r = env_size("MIRT_RAY_QUEUE", (size_t)32 << 20) / QUEUE_SHARDS;
+    size_t want_s = env_size("MIRT_SHADOW_QUEUE", (size_t)128 << 20) / QUEUE_SHARDS;
+    want_r = std::max(std::min(want_r, shard_blocks * 256 * K), min_blocks * 256 * K);
+    want_s = std::max(std::min(want_s, shard_blocks * 256 * S * std::max(K, 1)), min_blocks * 256 * S);
+    if (want_r * QUEUE_SHARDS > 0xfffffff0u || want_s * QUEUE_SHARDS > 0xfffffff0u)
+      return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
+    if (want_r > ws->ray_shard_cap) ws->ray_shard_cap = want_r;
+    if (want_s > ws->shadow_shard_cap) ws->shadow_shard_cap = want_s;
+    HIP_TRY(ws->shadow_items.reserve(ws->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem)));
     const void *before = ws->accum.p;
-    HIP_TRY(ws->accum.reserve(std::max<size_t>(n_pixels * 3 * sizeof(double), 64)));
+    HIP_TRY(ws->accum.reserve(accum_bytes));
     if (ws->accum.p != before) ws->accum_clean = false;
-  }
-  if (levels > 1) {
-    HIP_TRY(ensure_queue(ws, 0));
-    HIP_TRY(ensure_queue(ws, 1));
+    if (levels > 1) {
+      HIP_TRY(ensure_queue(ws, 0));
+      HIP_TRY(ensure_queue(ws, 1));
+    }
+  } else {
+    // The static array, cut up for this frame: control block | accumulator | shadow queue | two ray
+    // queues.  The queues share what the first two leave, in the proportion that lets a primary launch
+    // fill them evenly (S shadow items and one ray per sample); a frame whose smallest possible
+    // launch -- one pixel block, all samples -- does not fit is refused.
+    const size_t acc = (accum_bytes + 255) & ~(size_t)255;
+    if (kFixedControlBytes + acc >= MIRT_SCRATCH_BYTES)
+      return fail(MIRT_ERR_UNSUPPORTED, "frame of %zu pixels needs %zu bytes of accumulator: more than the %u-byte static "
+                  "working memory holds", n_pixels, acc, (unsigned)MIRT_SCRATCH_BYTES);
+    const size_t rest = MIRT_SCRATCH_BYTES - kFixedControlBytes - acc;
+    const size_t per_entry = (levels > 1 ? 2 * kRayBytes : 0) + (size_t)S * sizeof(DShadowItem);
+    size_t cap = rest / (QUEUE_SHARDS * per_entry);
+    cap -= cap % 256;
+    if (cap < min_blocks * 256 * (size_t)K)
+      return fail(MIRT_ERR_UNSUPPORTED, "frame too large for the static working memory: %zu pixels, %d samples, up to %d "
+                  "rays per hit leave room for %zu queue entries per shard, %zu needed", n_pixels, spp, K, cap,
+                  min_blocks * 256 * (size_t)K);
+    ws->ray_shard_cap = cap;
+    ws->shadow_shard_cap = cap * (size_t)S;
+    char *at = sc->scratch;
+    ws->control.borrow(at, kFixedControlBytes);
+    at += kFixedControlBytes;
+    ws->accum.borrow(at, acc);
+    at += acc;
+    const size_t shadow_bytes = ws->shadow_shard_cap * QUEUE_SHARDS * sizeof(DShadowItem);
+    ws->shadow_items.borrow(at, shadow_bytes);
+    at += shadow_bytes;
+    if (levels > 1) {
+      HIP_TRY(ensure_queue(ws, 0, at));
+      at += ws->ray_shard_cap * QUEUE_SHARDS * kRayBytes;
+      HIP_TRY(ensure_queue(ws, 1, at));
+    }
+    ws->accum_clean = false;  // the array keeps whatever the last call on this GPU left in it
   }
   // grid of the launches that consume a queue: fixed, the blocks stride over the queue
   const unsigned consumer_grid = (unsigned)std::min<size_t>(
@@ -760,6 +842,9 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   // tail counters: per primary launch and level, the rays and the shadow items that level queued
   const size_t stats_bytes = COUNTER_SHARDS * sizeof(DCounters);
   const size_t control_bytes = stats_bytes + chunks * (size_t)std::max(levels, 0) * 2 * kCountBytes;
+  if (ws->fixed && control_bytes > kFixedControlBytes)
+    return fail(MIRT_ERR_UNSUPPORTED, "frame too large for the static working memory: %zu primary launches x %d levels "
+                "need a %zu-byte control block, %zu available", chunks, levels, control_bytes, kFixedControlBytes);
   HIP_TRY(ws->control.reserve(control_bytes));
   HIP_TRY(ensure_pinned(ws, control_bytes));
   DCounters *counters = ws->control.as<DCounters>();
@@ -767,7 +852,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
     return reinterpret_cast<uint32_t *>(ws->control.as<char>() + stats_bytes +
                                         ((chunk * (size_t)levels + (size_t)level) * 2 + (size_t)what) * kCountBytes);
   };
-  const bool kernel_timing = config->kernel_timing != 0;
+  const bool kernel_timing = config->kernel_timing != 0 && !ws->fixed;  // per-launch events are created on demand
 
   size_t ev_used = 0;
   ws->timed.clear();
@@ -780,7 +865,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   HIP_TRY(get_event(ws, ev_used, ws->ev_end));
   HIP_TRY(hipEventRecord(ws->ev_begin, stream));
   HIP_TRY(hipMemsetAsync(ws->control.p, 0, control_bytes, stream));
-  if (n_pixels && !(ws->accum_clean && ws->accum_clean_bytes >= n_pixels * 3 * sizeof(double)))
+  if (n_pixels && !(ws->accum_clean && !ws->fixed && ws->accum_clean_bytes >= n_pixels * 3 * sizeof(double)))
     HIP_TRY(hipMemsetAsync(ws->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
   ws->accum_clean = false;
 
@@ -959,12 +1044,12 @@ int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
 int begin_frame(mirt_scene *sc, int slot, const mirt_camera *camera, const mirt_config *config, int width, int height,
                 int spp, int tile_w, int tile_h, int rank, int world, double *d_out, hipStream_t stream) {
   if (!sc || !camera || !config || !d_out) return fail(MIRT_ERR_INVALID, "NULL argument");
-  if (slot < 0 || slot > 1) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
+  if (slot < 0 || slot > 2) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
   if (width <= 0 || height <= 0 || spp <= 0) return fail(MIRT_ERR_INVALID, "width, height and spp must be positive");
   if (tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world)
     return fail(MIRT_ERR_INVALID, "bad tile split: tile %dx%d rank %d of %d", tile_w, tile_h, rank, world);
   if ((double)width * height * spp > 4.0e9) return fail(MIRT_ERR_UNSUPPORTED, "more than 4e9 samples in one frame");
-  mirt_scene::WorkSet *ws = &sc->work[slot];
+  mirt_scene::WorkSet *ws = slot == 2 ? &sc->fixed_work : &sc->work[slot];  // 2: the set that never allocates
   if (ws->pending) return fail(MIRT_ERR_INVALID, "slot %d still holds a frame: call mirt_render_tiles_end first", slot);
   HIP_TRY(hipSetDevice(sc->device));
   ws->camera = *camera;
@@ -978,6 +1063,12 @@ int begin_frame(mirt_scene *sc, int slot, const mirt_camera *camera, const mirt_
   ws->world = world;
   ws->d_out = d_out;
   ws->stream = stream ? stream : sc->stream;
+  if (!stream) {
+    // NULL means "the engine's own stream", which does not synchronise with the null stream by itself:
+    // make it wait for what the caller has already enqueued there (a fill of the output buffer, say)
+    HIP_TRY(hipEventRecord(sc->null_stream_mark, nullptr));
+    HIP_TRY(hipStreamWaitEvent(sc->stream, sc->null_stream_mark, 0));
+  }
   ws->attempts = 0;
   return enqueue_frame(sc, ws);
 }
@@ -996,6 +1087,7 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
 MIRT_API int mirt_render_tiles_begin(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
                                      int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
                                      double *d_rgb_out, void *stream, int slot) {
+  if (slot < 0 || slot > 1) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
   return begin_frame(scene, slot, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
                      static_cast<hipStream_t>(stream));
 }
@@ -1013,6 +1105,17 @@ MIRT_API int mirt_render_tiles(mirt_scene *scene, const mirt_camera *camera, con
   return render_device(scene, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
                        static_cast<hipStream_t>(stream), stats);
 }
+
+MIRT_API int mirt_render_tiles_noalloc(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
+                                       int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
+                                       double *d_rgb_out, void *stream, mirt_stats *stats) {
+  if (int rc = begin_frame(scene, 2, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
+                           static_cast<hipStream_t>(stream)))
+    return rc;
+  return finish_frame(scene, &scene->fixed_work, stats);
+}
+
+MIRT_API uint64_t mirt_noalloc_scratch_bytes(void) { return MIRT_SCRATCH_BYTES; }
 
 MIRT_API int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
                          int height, int spp, double *rgb_out, mirt_stats *stats) {

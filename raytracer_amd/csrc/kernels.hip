@@ -63,3 +63,27 @@ void launch_trace_rays(int walk, unsigned grid, void *stream, const RaysArgs &a)
           hipLaunchKernelGGL(k_trace_rays<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
           hipLaunchKernelGGL(k_trace_rays<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a));
 }
+
+// ---- working memory for the entry point that allocates nothing ----------------------------------
+// One array per GPU, held from the moment the code object is loaded until the process ends.  In host
+// code the array's name is only a handle for the runtime: the memory's device address is asked for
+// once per device (with that device current) and everything -- kernel arguments, fills, copies --
+// uses that address.  Every call on a GPU shares that GPU's array; calls that overlap on one GPU race.
+static __device__ __align__(256) unsigned char scratch[MIRT_SCRATCH_BYTES];
+
+#define MIRT_SCRATCH_MAX_DEVICES 64
+static void *g_scratch_ptr[MIRT_SCRATCH_MAX_DEVICES];
+
+// Device address of `device`'s copy of the array; `device` must be the current device.
+int scratch_address(int device, void **out) {
+  if (device < 0 || device >= MIRT_SCRATCH_MAX_DEVICES) return (int)hipErrorInvalidDevice;
+  if (!g_scratch_ptr[device]) {
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!p) return (int)hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return 0;
+}
