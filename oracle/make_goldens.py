@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 FIX = os.path.join(ROOT, "fixtures")
 OUT = os.path.join(ROOT, "tests", "golden")
-SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene"]
+# the reference's eight scenes, Test7 with a glass sphere added (the 64-spp depth-of-field configuration) and a
+# hand-written scene whose sphere, cube and plane carry normal maps (no bundled scene has one)
+SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene", "Test7_glass", "NormalMap"]
 W, H = 96, 54  # deterministic (pixel-centre) maps
 SYNTHETIC = [("synthetic100k", 100000, 0x5EED)]  # generated scenes (raytracer_amd/host/synthetic.h): a deep BVH
 
@@ -33,6 +35,22 @@ RENDERS = [
     ("t4_glossy3", "Test4", 64, 36, 2, ["--max-depth", "6", "--glossy", "3"]),
     ("t1_cfg0", "Test1", 80, 60, 1, ["--max-depth", "3"]),
     ("t5_nomb_seed7", "Test5", 64, 36, 2, ["--max-depth", "5", "--motion-blur", "0", "--seed", "7"]),
+    ("t7g_cfg5", "Test7_glass", 48, 27, 2, ["--max-depth", "8", "--glossy", "4", "--shadow-samples", "16",
+                                           "--dof", "0.95", "16.12"]),
+    ("nm_default", "NormalMap", 64, 36, 2, ["--max-depth", "4"]),
+    ("nm_notex", "NormalMap", 64, 36, 1, ["--max-depth", "3", "--textures", "0"]),
+]
+
+# frames of Raytracer::render ITSELF (harness `render-real`: one thread, one random stream through the
+# whole frame): (name, scene, w, h, spp, flags); they pin the render loop, tone mapping and gamma
+REAL_RENDERS = [
+    ("real_t5_none", "Test5", 48, 27, 2, ["--max-depth", "5"]),
+    ("real_t5_reinhard", "Test5", 48, 27, 2, ["--max-depth", "5", "--tone-mapping", "reinhard"]),
+    ("real_t5_exposure", "Test5", 48, 27, 2, ["--max-depth", "5", "--tone-mapping", "exposure", "--exposure", "1.7"]),
+    ("real_t4_exposure_nogamma", "Test4", 48, 27, 1, ["--max-depth", "4", "--tone-mapping", "exposure", "--exposure",
+                                                      "2.5", "--gamma-correction", "0"]),
+    ("real_t7_dof", "Test7", 32, 18, 1, ["--max-depth", "4", "--shadow-samples", "4", "--dof", "0.95", "16.12"]),
+    ("real_nm", "NormalMap", 48, 27, 1, ["--max-depth", "3"]),
 ]
 
 
@@ -73,12 +91,13 @@ def main():
                 normal=rest[n: 4 * n].reshape(n, 3), point=rest[4 * n: 7 * n].reshape(n, 3),
                 uv=rest[7 * n: 9 * n].reshape(n, 2), trace_rgb_depth5=rgb.reshape(n, 3))
             print(s, "hit fraction", float((ids >= 0).mean()))
-        for name, s, w, h, spp, flags in RENDERS:
+        jobs = [("render", "render_", r) for r in RENDERS] + [("render-real", "", r) for r in REAL_RENDERS]
+        for cmd, prefix, (name, s, w, h, spp, flags) in jobs:
             out = os.path.join(tmp, "r.bin")
-            _, err = harness("render", f"ASCII/{s}.txt", str(w), str(h), str(spp), out, *flags)
+            _, err = harness(cmd, f"ASCII/{s}.txt", str(w), str(h), str(spp), out, *flags)
             prim_tests = int(err.split()[1])
             rgb = np.fromfile(out, dtype=np.float64).reshape(h * w, 3)
-            np.savez_compressed(os.path.join(OUT, f"render_{name}.npz"), width=w, height=h, spp=spp, rgb=rgb,
+            np.savez_compressed(os.path.join(OUT, f"{prefix}{name}.npz"), width=w, height=h, spp=spp, rgb=rgb,
                                 prim_tests=prim_tests)
             print(name, "mean", float(rgb.mean()), "prim_tests", prim_tests)
     np.savez_compressed(os.path.join(OUT, "dumps.npz"), **dumps)

@@ -14,6 +14,10 @@
 //                          reference's depth-first order -- comparable with ref_harness
 //   ORACLE_RNG_KEYED       every draw addressed by (ray-tree node key, dimension) -- comparable
 //                          with the HIP engine
+//   ORACLE_RNG_FRAME       one stream for the whole frame: draw n of the frame is
+//                          mirt_rng_bits(K0, n), K0 the key of (pixel 0, sample 0), consumed in the
+//                          order in which ONE thread runs the reference's render loop -- comparable
+//                          with Raytracer::render itself (ref_harness `render-real`)
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -27,7 +31,7 @@
 
 namespace {
 
-enum { ORACLE_RNG_SEQUENTIAL = 0, ORACLE_RNG_KEYED = 1 };
+enum { ORACLE_RNG_SEQUENTIAL = 0, ORACLE_RNG_KEYED = 1, ORACLE_RNG_FRAME = 2 };
 
 struct Ray {  // Core/Ray.h:6-17
   Point origin;
@@ -62,7 +66,7 @@ struct Rng {
   uint64_t seq_key = 0;
   uint32_t n = 0;
   double draw(uint64_t key, uint32_t dim) {
-    return mode == ORACLE_RNG_SEQUENTIAL ? mirt_rng_draw(seq_key, n++) : mirt_rng_draw(key, dim);
+    return mode == ORACLE_RNG_KEYED ? mirt_rng_draw(key, dim) : mirt_rng_draw(seq_key, n++);
   }
 };
 
@@ -1020,23 +1024,35 @@ int oracle_trace_ids(const mirt_scene_desc *sc, const mirt_camera *cam_in, int w
   return 0;
 }
 
-// The render loop of Raytracer.cpp:526-571.  rgb_out: height*width*3 doubles as Image.pixels holds
-// them (mean over spp, tone map, gamma).  rng_mode: ORACLE_RNG_SEQUENTIAL or ORACLE_RNG_KEYED.
-int oracle_render(const mirt_scene_desc *sc, const mirt_camera *cam, const mirt_config *cfg, int width, int height,
-                  int spp, int rng_mode, double *rgb_out, oracle_stats *stats) {
+// The render loop of Raytracer.cpp:526-571 over the window [x0, x0+w) x [y0, y0+h) of a width x height
+// frame (pixel keys are those of the full frame, so a window is a crop of the full render).
+// rgb_out: h*w*3 doubles as Image.pixels holds them (mean over spp, tone map, gamma).
+// rng_mode: ORACLE_RNG_SEQUENTIAL, ORACLE_RNG_KEYED or ORACLE_RNG_FRAME (single thread, rows in order).
+int oracle_render_window(const mirt_scene_desc *sc, const mirt_camera *cam, const mirt_config *cfg, int width,
+                         int height, int spp, int rng_mode, int x0, int y0, int w, int h, double *rgb_out,
+                         oracle_stats *stats) {
   if (!sc || !cam || !cfg || !rgb_out || width <= 0 || height <= 0 || spp <= 0) return -1;
+  if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > width || y0 + h > height) return -1;
   uint64_t c_pri = 0, c_sec = 0, c_sh = 0, c_node = 0, c_prim = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c_pri, c_sec, c_sh, c_node, c_prim)
-  for (int y = 0; y < height; y++) {
+  const bool frame_stream = rng_mode == ORACLE_RNG_FRAME;
+  Rng frame_rng;  // ORACLE_RNG_FRAME: the one stream, carried from row to row
+  frame_rng.mode = rng_mode;
+  frame_rng.seq_key = mirt_rng_sample_key(cfg->seed, 0, 0);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c_pri, c_sec, c_sh, c_node, c_prim) if (!frame_stream)
+  for (int y = y0; y < y0 + h; y++) {
     Ctx cx{sc, cfg, {}, {}};
     cx.rng.mode = rng_mode;
-    for (int x = 0; x < width; x++) {
+    if (frame_stream) cx.rng = frame_rng;
+    for (int x = x0; x < x0 + w; x++) {
       const size_t i = (size_t)y * width + x;
+      const size_t o = (size_t)(y - y0) * w + (x - x0);
       Color px(0, 0, 0);
       for (int s = 0; s < spp; s++) {
         const uint64_t key = mirt_rng_sample_key(cfg->seed, (uint32_t)i, (uint32_t)s);
-        cx.rng.seq_key = key;
-        cx.rng.n = 0;
+        if (!frame_stream) {
+          cx.rng.seq_key = key;
+          cx.rng.n = 0;
+        }
         double u, v, time;
         if (cfg->sampling == MIRT_SAMPLING_CENTRE) {
           u = x + 0.5;
@@ -1051,26 +1067,27 @@ int oracle_render(const mirt_scene_desc *sc, const mirt_camera *cam, const mirt_
         px += trace(cx, ray, 0, key);
       }
       px /= spp;
-      if (cfg->tone_mapping_mode == MIRT_TONEMAP_REINHARD) {
+      if (cfg->tone_mapping_mode == MIRT_TONEMAP_REINHARD) {  // Raytracer.cpp:547-551
         px.x = px.x / (1.0 + px.x);
         px.y = px.y / (1.0 + px.y);
         px.z = px.z / (1.0 + px.z);
-      } else if (cfg->tone_mapping_mode == MIRT_TONEMAP_EXPOSURE) {
+      } else if (cfg->tone_mapping_mode == MIRT_TONEMAP_EXPOSURE) {  // Raytracer.cpp:552-559
         px *= cfg->exposure;
         px.x = std::min(1.0, px.x);
         px.y = std::min(1.0, px.y);
         px.z = std::min(1.0, px.z);
       }
-      if (cfg->enable_gamma_correction) {
+      if (cfg->enable_gamma_correction) {  // Raytracer.cpp:563-568
         const double gi = 1.0 / cfg->gamma;
         px.x = std::pow(px.x, gi);
         px.y = std::pow(px.y, gi);
         px.z = std::pow(px.z, gi);
       }
-      rgb_out[3 * i] = px.x;
-      rgb_out[3 * i + 1] = px.y;
-      rgb_out[3 * i + 2] = px.z;
+      rgb_out[3 * o] = px.x;
+      rgb_out[3 * o + 1] = px.y;
+      rgb_out[3 * o + 2] = px.z;
     }
+    if (frame_stream) frame_rng = cx.rng;
     c_pri += cx.cnt.primary;
     c_sec += cx.cnt.secondary;
     c_sh += cx.cnt.shadow_segments;
@@ -1085,6 +1102,12 @@ int oracle_render(const mirt_scene_desc *sc, const mirt_camera *cam, const mirt_
     stats->prim_tests = c_prim;
   }
   return 0;
+}
+
+// The whole frame.
+int oracle_render(const mirt_scene_desc *sc, const mirt_camera *cam, const mirt_config *cfg, int width, int height,
+                  int spp, int rng_mode, double *rgb_out, oracle_stats *stats) {
+  return oracle_render_window(sc, cam, cfg, width, height, spp, rng_mode, 0, 0, width, height, rgb_out, stats);
 }
 
 // intersect_bvh (Bvh.cpp:306) for caller-supplied rays; time / t_max may be NULL (0.5 / DBL_MAX).

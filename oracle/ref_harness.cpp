@@ -18,12 +18,16 @@
 //   dump-bvh   <scene>                 preorder dump of the reference BVH        -> stdout
 //   hits   <scene> W H out.bin         closest hit of pixel-centre rays (time 0.5)
 //   trace  <scene> W H out.bin [opts]  Raytracer::trace() of pixel-centre rays (linear RGB)
-//   render <scene> W H SPP out.bin [opts]  the render loop of Raytracer.cpp:526-571 with the
-//                                      hooked generators (post-gamma RGB, as Image.pixels)
+//   render <scene> W H SPP out.bin [opts]  the render loop of Raytracer.cpp:526-571 re-typed here so
+//                                      that the hooked stream restarts at every primary sample
+//                                      (post-gamma RGB, as Image.pixels)
+//   render-real <scene> W H SPP out.bin [opts]  Raytracer::render itself (Raytracer.cpp:475-607) on one
+//                                      thread; the hooked stream runs on through the whole frame
 #define private public
 #include "Render/Raytracer.h"
 #undef private
 
+#include <omp.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -245,7 +249,8 @@ static int usage() {
   std::fprintf(stderr,
                "usage: ref_harness --root DIR <dump-scene|dump-bvh|hits|trace|render> <scene> [W H [SPP] out] "
                "[--max-depth n] [--shadow-samples n] [--glossy n] [--motion-blur 0|1] [--textures 0|1] "
-               "[--dof a d | --no-dof] [--light-intensity f] [--ambient f] [--seed n] [--threads n]\n");
+               "[--dof a d | --no-dof] [--light-intensity f] [--ambient f] [--seed n] "
+               "[--tone-mapping none|reinhard|exposure] [--exposure f] [--gamma-correction 0|1]\n");
   return 1;
 }
 
@@ -271,6 +276,9 @@ int main(int argc, char **argv) {
     else if (a == "--light-intensity") { need(1); g_config.light_intensity_factor = std::atof(argv[++i]); }
     else if (a == "--ambient") { need(1); g_config.ambient_factor = std::atof(argv[++i]); }
     else if (a == "--seed") { need(1); o.seed = std::strtoull(argv[++i], nullptr, 10); }
+    else if (a == "--tone-mapping") { need(1); g_config.tone_mapping_mode = argv[++i]; }
+    else if (a == "--exposure") { need(1); g_config.exposure = std::atof(argv[++i]); }
+    else if (a == "--gamma-correction") { need(1); g_config.enable_gamma_correction = std::atoi(argv[++i]) != 0; }
     else pos.push_back(a);
   }
   if (pos.size() < 2) return usage();
@@ -393,6 +401,31 @@ int main(int argc, char **argv) {
     std::fclose(f);
     std::fprintf(stderr, "prim_tests %lld seconds %.6f\n", g_intersection_tests,
                  std::chrono::duration<double>(t1 - t0).count());
+    return 0;
+  }
+  if (cmd == "render-real" && pos.size() == 6) {
+    // The reference's own render loop, untouched.  One OpenMP thread, so rows run in order and the
+    // two hooked generators (thread_local in the reference) consume one stream front to back.
+    const int W = std::atoi(pos[2].c_str()), H = std::atoi(pos[3].c_str());
+    const int spp = std::max(1, std::atoi(pos[4].c_str()));
+    setenv("OMP_NUM_THREADS", "1", 1);  // so that Raytracer.cpp:479-485 keeps the thread count set here
+    omp_set_num_threads(1);
+    stream_begin(mirt_rng_sample_key(o.seed, 0, 0));
+    g_intersection_tests = 0;
+    FILE *keep = std::freopen("/dev/null", "w", stdout);  // the progress bar
+    (void)keep;
+    Image img = rt.render(cam, W, H, spp);
+    std::vector<double> rgb(3 * (size_t)W * H);
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        const size_t i = (size_t)y * W + x;
+        rgb[3 * i] = img.pixels[y][x].x; rgb[3 * i + 1] = img.pixels[y][x].y; rgb[3 * i + 2] = img.pixels[y][x].z;
+      }
+    FILE *f = std::fopen(pos[5].c_str(), "wb");
+    if (!f) { std::perror("fopen"); return 1; }
+    wr(f, rgb);
+    std::fclose(f);
+    std::fprintf(stderr, "prim_tests %lld\n", g_intersection_tests);
     return 0;
   }
   return usage();

@@ -14,7 +14,8 @@ def pytest_configure(config):
 
 FIXTURES = os.path.join(ROOT, "fixtures")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene"]
+# the reference's eight scenes, Test7 with a glass sphere added, and a hand-written scene with normal maps
+SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene", "Test7_glass", "NormalMap"]
 # generated scenes (raytracer_amd/host/synthetic.h): name -> (primitives, seed); oracle/make_goldens.py
 # feeds the same scenes to the reference as ASCII files
 SYNTHETIC = {"synthetic100k": (100000, 0x5EED)}

@@ -8,7 +8,7 @@ import numpy as np
 from raytracer_amd import _abi as A
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RNG_SEQUENTIAL, RNG_KEYED = 0, 1
+RNG_SEQUENTIAL, RNG_KEYED, RNG_FRAME = 0, 1, 2
 
 
 class OracleStats(C.Structure):
@@ -34,6 +34,9 @@ def lib():
                                           dp, dp, ip]
         _lib.oracle_render.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.Camera), C.POINTER(A.Config), C.c_int,
                                        C.c_int, C.c_int, C.c_int, dp, C.POINTER(OracleStats)]
+        _lib.oracle_render_window.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.Camera), C.POINTER(A.Config), C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp,
+                                              C.POINTER(OracleStats)]
         _lib.oracle_trace_rays.argtypes = [C.POINTER(A.SceneDesc), C.c_int64, dp, dp, dp, C.c_double, dp, ip, dp, dp]
         _lib.oracle_max_threads.restype = C.c_int
     return _lib
@@ -64,6 +67,16 @@ def render(desc, camera, config, width, height, spp, rng_mode=RNG_KEYED):
     st = OracleStats()
     rc = lib().oracle_render(C.byref(desc), C.byref(camera), C.byref(config), width, height, spp, rng_mode,
                              rgb.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st))
+    assert rc == 0
+    return rgb, st.as_dict()
+
+
+def render_window(desc, camera, config, width, height, spp, x0, y0, w, h, rng_mode=RNG_KEYED):
+    """The window [x0, x0+w) x [y0, y0+h) of the width x height frame: a crop of render()'s frame."""
+    rgb = np.empty((h, w, 3))
+    st = OracleStats()
+    rc = lib().oracle_render_window(C.byref(desc), C.byref(camera), C.byref(config), width, height, spp, rng_mode,
+                                    x0, y0, w, h, rgb.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st))
     assert rc == 0
     return rgb, st.as_dict()
 

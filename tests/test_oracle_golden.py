@@ -8,7 +8,7 @@ import pytest
 
 import oracle_lib as O
 from conftest import GOLDEN, SCENES, SYNTHETIC
-from golden_cases import RENDER_CASES
+from golden_cases import REAL_CASES, RENDER_CASES
 from raytracer_amd import default_config
 
 
@@ -51,6 +51,33 @@ def test_stochastic_render_bit_exact(case, host_scenes):
     rgb, st = O.render(hs.desc, cam, cfg, w, h, spp, O.RNG_SEQUENTIAL)
     assert np.array_equal(rgb.reshape(-1, 3), gold["rgb"])
     assert st["prim_tests"] == int(gold["prim_tests"])  # g_intersection_tests of the reference
+
+
+@pytest.mark.parametrize("case", sorted(REAL_CASES))
+def test_frames_of_the_reference_render_function_bit_exact(case, host_scenes):
+    """Raytracer::render ITSELF (Raytracer.cpp:475-607: sample loop, mean, Reinhard / exposure tone
+    mapping, gamma) run on one thread with its two generators fed one stream through the whole frame,
+    against the oracle consuming the same stream in the same order."""
+    scene, dof, over = REAL_CASES[case]
+    hs = host_scenes(scene)
+    gold = np.load(os.path.join(GOLDEN, f"{case}.npz"))
+    w, h, spp = int(gold["width"]), int(gold["height"]), int(gold["spp"])
+    cam, _ = hs.camera(0, dof=dof)
+    cfg = default_config(**over)
+    rgb, st = O.render(hs.desc, cam, cfg, w, h, spp, O.RNG_FRAME)
+    assert np.array_equal(rgb.reshape(-1, 3), gold["rgb"])
+    assert st["prim_tests"] == int(gold["prim_tests"])
+
+
+def test_a_window_is_a_crop_of_the_frame(host_scenes):
+    hs = host_scenes("Test5")
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=5, glossy_samples=2)
+    for mode in (O.RNG_KEYED, O.RNG_SEQUENTIAL):
+        full, _ = O.render(hs.desc, cam, cfg, 64, 36, 2, mode)
+        win, st = O.render_window(hs.desc, cam, cfg, 64, 36, 2, 20, 9, 17, 11, mode)
+        assert np.array_equal(win, full[9:20, 20:37])
+        assert st["primary_rays"] == 17 * 11 * 2
 
 
 def test_keyed_and_sequential_agree_without_randomness(host_scenes):
