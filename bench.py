@@ -32,24 +32,40 @@ sys.path.insert(0, ROOT)
 # primitive records the ray tests (N_node, N_prim are measured by the engine's counters)
 RAY_B, HIT_B, NODE_B, PRIM_B = 64, 32, 64, 128
 HBM_PEAK_GBS = 8000.0
+# vector issue capacity of the chip: 256 CUs x 4 SIMDs at 2.4 GHz.  A 64-lane vector instruction
+# occupies its SIMD for 2 cycles, a double-precision one for 4 (157 / 79 TFLOP/s vector peaks).
+SIMDS, CLOCK_GHZ = 1024, 2.4
+CYC_F64, CYC_OTHER = 4.0, 2.0
 
 
 def bytes_per_ray(n_node, n_prim):
     return 2 * RAY_B + 2 * HIT_B + n_node * NODE_B + n_prim * PRIM_B
 
 
-def cpu_baseline(scene_name, width, height, spp, depth, rays_per_sample):
-    """Times the CPU path on a bounded sample of the same workload (rank 0, N = 1 only).
-    Prefers the unmodified reference CLI built by oracle/Makefile (kind "reference"); without it the
-    CPU restatement in oracle/ is timed (kind "port")."""
+def cpu_baseline(args, rays_per_sample):
+    """Times the CPU path on the same workload (rank 0, N = 1 only): the unmodified reference program
+    built by oracle/Makefile (kind "reference") renders the whole bench frame where that takes seconds
+    (Test5), a stated fraction of its pixels where it would take minutes (the 64-spp configuration); the
+    generated cloud, which the reference could only read as a gigabyte of text, and a box without the
+    reference build time the CPU restatement in oracle/ instead (kind "port")."""
     cores = int(os.environ.get("OMP_NUM_THREADS") or min(os.cpu_count() or 1, 16))
     ref = os.path.join(ROOT, "oracle", "_ref", "raytracer_ref")
-    sample = f"{scene_name} {width}x{height} {spp} spp max-depth {depth} (the bench frame at 1/4 of its pixels)"
-    if os.path.exists(ref):
+    scene_name, spp, depth = args.scene, args.spp, args.max_depth
+    shrink = 4 if spp > 16 else 1  # per axis
+    width, height = args.width // shrink, args.height // shrink
+    sample = (f"{scene_name} {width}x{height} {spp} spp max-depth {depth}: "
+              + ("the whole bench frame" if shrink == 1 else f"the bench frame at 1/{shrink * shrink} of its pixels"))
+    if os.path.exists(ref) and not scene_name.startswith("synthetic:"):
         with tempfile.TemporaryDirectory() as tmp:
             env = dict(os.environ, OMP_NUM_THREADS=str(cores))
             cmd = [ref, "--scene", os.path.join("ASCII", f"{scene_name}.txt"), "--resolution", str(width), str(height),
                    "--samples", str(spp), "--max-depth", str(depth), "--output", os.path.join(tmp, "cpu.ppm")]
+            if args.glossy_reflection:
+                cmd += ["--glossy-reflection", str(args.glossy_reflection)]
+            if args.soft_shadows is not None:
+                cmd += ["--soft-shadows", str(args.soft_shadows)]
+            if args.depth_of_field:
+                cmd += ["--depth-of-field", str(args.depth_of_field[0]), str(args.depth_of_field[1])]
             r = subprocess.run(cmd, cwd=os.path.join(ROOT, "fixtures"), env=env, capture_output=True, text=True)
             m = re.search(r"seconds=([0-9.]+)\s+Render time|Render time.*?seconds=([0-9.]+)", r.stdout)
             if r.returncode == 0 and m:
@@ -57,16 +73,28 @@ def cpu_baseline(scene_name, width, height, spp, depth, rays_per_sample):
                 if sec > 0:
                     return {"value": width * height * spp * rays_per_sample / sec / 1e6, "unit": "Mrays/s",
                             "cores": cores, "kind": "reference", "seconds": sec,
-                            "sample": sample + "; ray count = samples x the engine's measured rays per sample"}
+                            "sample": sample + "; timed by the reference's own 'Render time' line; rays = samples x "
+                                      "the rays per sample the engine counted on the same workload (the reference "
+                                      "counts none)"}
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         from raytracer_amd import HostScene, default_config
-        hs = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{scene_name}.txt"))
-        cam, _ = hs.camera(0)
-        cfg = default_config(max_ray_depth=depth)
+        if scene_name.startswith("synthetic:"):
+            hs = HostScene.synthetic(int(scene_name.split(":")[1]))
+            win = (args.width // 2 - 240, args.height // 2 - 135, 480, 270)  # a window of the frame
+            sample = f"{scene_name} {args.width}x{args.height} {spp} spp max-depth {depth}: window {win} of the bench frame"
+        else:
+            hs = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{scene_name}.txt"))
+            win = (0, 0, width, height)
+        cam, _ = hs.camera(0, dof=tuple(args.depth_of_field) if args.depth_of_field else None)
+        over = dict(max_ray_depth=depth, glossy_samples=args.glossy_reflection or 0)
+        if args.soft_shadows is not None:
+            over["shadow_samples"] = args.soft_shadows
+        cfg = default_config(**over)
+        full = (args.width, args.height) if scene_name.startswith("synthetic:") else (width, height)
         t0 = time.perf_counter()
-        _, st = O.render(hs.desc, cam, cfg, width, height, spp, O.RNG_KEYED)
+        _, st = O.render_window(hs.desc, cam, cfg, full[0], full[1], spp, *win, O.RNG_KEYED)
         sec = time.perf_counter() - t0
         return {"value": (st["primary_rays"] + st["secondary_rays"]) / sec / 1e6, "unit": "Mrays/s",
                 "cores": O.lib().oracle_max_threads(), "kind": "port", "seconds": sec, "sample": sample}
@@ -84,17 +112,17 @@ PRESETS = {
 }
 
 
-def hbm_traffic(kernel, workload):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json, written by
-    profiles/traffic_summary.py from rocprofv3 FETCH_SIZE / WRITE_SIZE passes), if it is for this workload."""
+def counter_model(kernel, workload):
+    """What the committed counter passes say about `kernel` on this workload (profiles/kernel_model.json,
+    written by profiles/kernel_model.py from rocprofv3 --pmc runs of this same command): HBM bytes per
+    launch (FETCH_SIZE / WRITE_SIZE), vector instructions per ray or shadow segment and the share of them
+    that is double precision.  None when no pass was collected for the workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "kernel_model.json")) as f:
             t = json.load(f)
-        if t.get("workload") == workload and kernel in t.get("kernels", {}):
-            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+        return t[workload]["kernels"][kernel]
     except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return None
 
 
 def main():
@@ -169,6 +197,8 @@ def main():
     else:
         bufs = [torch.empty(W * H * 3, dtype=torch.float64, device=device) for _ in range(depth)]
     streams = [torch.cuda.Stream(device) for _ in range(depth)]
+    for st_ in streams:  # the buffers were made (and zero-filled) on the current stream
+        st_.wait_stream(torch.cuda.current_stream(device))
     frames = [None] * depth
     gather_to = [0]  # rank that receives the frame; None: all-gather (fallback if the backend lacks gather)
 
@@ -238,8 +268,13 @@ def main():
     acc = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    cfg.kernel_timing = 1
+    # latency of one frame: the same frames one at a time (enqueue, wait, next)
     n_timed = args.steps if world == 1 else 1
+    t0 = time.perf_counter()
+    run(n_timed, depth=1)
+    barrier()
+    latency = (time.perf_counter() - t0) / n_timed
+    cfg.kernel_timing = 1
     st = run(n_timed, depth=1)
     for k in ("trace_kernel_ms", "shadow_kernel_ms", "trace_kernel_launches", "shadow_kernel_launches"):
         acc[k] = st[k] * (args.steps / n_timed)
@@ -250,12 +285,13 @@ def main():
     red_dev = "cpu" if rehearsal else device
     tot = torch.tensor([float(acc[k]) for k in keys] + [acc["trace_kernel_ms"], acc["shadow_kernel_ms"]],
                        dtype=torch.float64, device=red_dev)
-    tmax = torch.tensor([elapsed, acc["trace_kernel_ms"], acc["shadow_kernel_ms"]], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([elapsed, acc["trace_kernel_ms"], acc["shadow_kernel_ms"], latency], dtype=torch.float64,
+                        device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tot = dict(zip(keys + ["trace_kernel_ms", "shadow_kernel_ms"], tot.tolist()))
-    elapsed = float(tmax[0])
+    elapsed, latency = float(tmax[0]), float(tmax[3])
 
     if rank == 0:
         steps = args.steps
@@ -276,7 +312,21 @@ def main():
                     + (f" glossy {args.glossy_reflection}" if args.glossy_reflection else "")
                     + (f" soft-shadows {args.soft_shadows}" if args.soft_shadows is not None else "")
                     + (f" dof {args.depth_of_field[0]} {args.depth_of_field[1]}" if args.depth_of_field else ""))
-        traffic = hbm_traffic(name, workload) if world == 1 else None
+        # The bound that binds is vector issue, most of it double precision: the scenes are a few KB
+        # and sit in the scalar cache, so charging every node and primitive test as memory traffic
+        # (the algorithmic-bytes figure) overshoots what reaches HBM several times.  `frac` prices the
+        # kernel's vector instructions -- counted per ray / shadow segment by the committed counter
+        # passes, times the rays this run counted -- against the chip's issue capacity over the
+        # measured launch time; hbm_frac does the same with the measured HBM bytes.
+        model = counter_model(name, workload) if world == 1 else None
+        units_per_launch = q / max(launches, 1)
+        traffic = issue = hbm_frac = None
+        if model and avg_ms > 0:
+            traffic = model["hbm_bytes_per_unit"] * units_per_launch
+            hbm_frac = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            cyc = model["valu_per_unit"] * (model["fp64_share"] * CYC_F64 + (1.0 - model["fp64_share"]) * CYC_OTHER)
+            issue = cyc * units_per_launch / (avg_ms * 1e-3) / 1e9  # G SIMD-cycles of vector issue per second
+        peak_issue = SIMDS * CLOCK_GHZ
         line = {
             "metric": f"Mrays/s (primary+secondary) at {W}x{H}x{spp}spp depth {args.max_depth}",
             "value": rays_ps / elapsed / 1e6,
@@ -285,28 +335,37 @@ def main():
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
+            "frame_latency_ms": latency * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic" if not (world > 1 and rehearsal) else "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)",
+            "data": ("synthetic" if args.scene.startswith("synthetic:") else "fixture")
+                    + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if world > 1 and rehearsal else ""),
             "config": {"workload": workload, "preset": args.config, "tile": tile if world > 1 else None,
                        "parallelism": f"tiles/{world}", "frames_in_flight": depth},
             "mrays_all_per_s": rays_all / elapsed / 1e6,
             "rays_per_sample": rays_ps / max(tot["primary_rays"], 1),
             "shadow_segments_per_sample": tot["shadow_segments"] / max(tot["primary_rays"], 1),
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray": b_ray, "node_tests_per_ray": nn / max(q, 1),
-                         "prim_tests_per_ray": npr / max(q, 1), "rays_per_launch": q / max(launches, 1),
-                         "avg_launch_ms": avg_ms,
+            "roofline": {"bound": "valu_fp64", "kernel": name, "achieved": issue, "peak": peak_issue,
+                         "unit": "G SIMD-cycles/s of vector issue",
+                         "frac": issue / peak_issue if issue is not None else None,
+                         "traffic": traffic, "hbm_frac": hbm_frac, "hbm_peak_gbs": HBM_PEAK_GBS,
+                         "algorithmic_gbs": achieved, "bytes_per_ray": b_ray,
+                         "node_tests_per_ray": nn / max(q, 1), "prim_tests_per_ray": npr / max(q, 1),
+                         "rays_per_launch": units_per_launch, "avg_launch_ms": avg_ms,
+                         "valu_per_ray": model["valu_per_unit"] if model else None,
+                         "fp64_share": model["fp64_share"] if model else None,
+                         "counters_from": model["source"] if model else None,
                          "timed_on": f"{n_timed} frame(s) rendered one at a time after the timed region",
-                         "note": "algorithmic bytes charge every node and primitive test as memory traffic; a scene "
-                                 "that stays in the scalar cache / L2 can therefore exceed the HBM peak -- traffic "
-                                 "is the measured HBM bytes per launch"},
+                         "note": "ms_per_step is the interval between frames with two in flight, frame_latency_ms one "
+                                 "frame alone; frac = vector issue cycles (double precision 4, other 2 per wave "
+                                 "instruction) / (1024 SIMDs x 2.4 GHz x launch time); hbm_frac = measured HBM bytes "
+                                 "/ launch time / 8 TB/s; algorithmic_gbs charges every node and primitive test as "
+                                 "memory traffic and is not a fraction of anything (the scene stays in cache)"},
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
-            line["cpu_baseline"] = cpu_baseline(args.scene, W // 2, H // 2, spp, args.max_depth, line["rays_per_sample"])
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, line["rays_per_sample"])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

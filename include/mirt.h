@@ -283,8 +283,11 @@ uint64_t mirt_noalloc_scratch_bytes(void);
  * same order per ray as intersect_bvh (Bvh.cpp:306-333) and return the same hits, exact ties included.
  * ORDERED (per ray, nearer child first, farther child on a per-lane stack) tests fewer boxes; it
  * returns the same closest hit except that two surfaces at exactly the same distance may swap.
+ * WIDE walks the same tree collapsed into 4-wide nodes, nearer child first like ORDERED, and runs the primitive
+ * tests a kind at a time across the wave: the walk for large scenes (same closest hit, exact ties may swap).
  * AUTO: PACKET up to a few hundred primitives, LANE above. */
-enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE = 2, MIRT_TRAVERSAL_ORDERED = 3 };
+enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE = 2, MIRT_TRAVERSAL_ORDERED = 3,
+       MIRT_TRAVERSAL_WIDE = 4 };
 int mirt_scene_set_traversal(mirt_scene *scene, int mode);
 
 const char *mirt_last_error(void);

@@ -123,7 +123,7 @@ class DeviceScene:
     def set_traversal(self, mode):
         """mode: "auto", "packet" (wave-coherent BVH walk), "lane" (one walk per ray, the reference's
         order) or "ordered" (one walk per ray, nearer child first)."""
-        code = {"auto": 0, "packet": 1, "lane": 2, "ordered": 3}[mode]
+        code = {"auto": 0, "packet": 1, "lane": 2, "ordered": 3, "wide": 4}[mode]
         _check(self._lib.mirt_scene_set_traversal(self._h, code), "mirt_scene_set_traversal")
 
     def close(self):

@@ -30,7 +30,37 @@ struct alignas(64) DNode {
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte record");
 
 // BVH walks (see pipeline.h)
-enum : int32_t { WALK_PACKET = 0, WALK_LANE = 1, WALK_ORDERED = 2 };
+enum : int32_t { WALK_PACKET = 0, WALK_LANE = 1, WALK_ORDERED = 2, WALK_WIDE = 3 };
+// leaf_tagged: leaf_prims with the primitive's kind in the top bits, for the walk that batches by kind
+#define LEAF_KIND_SHIFT 28
+#define LEAF_PRIM_MASK 0x0fffffff
+
+// The wide walk's view of the same tree: the binary nodes collapsed two levels at a time.
+//   DWide  128 B  four slots: the grandchildren of a binary inner node (a child that is a leaf fills
+//                 one slot of its pair and leaves the other empty), boxes rounded outwards to float;
+//                 child >= 0: wide node, < 0: ~index of a DLeaf; an empty slot has an inverted box,
+//                 which no ray hits.  order: 3 bits for the binary node itself, 3 for its first
+//                 child, 3 for its second (DNode::order of each).
+//   DLeaf   64 B  a binary leaf: its exact box and up to four primitives (index | kind <<
+//                 LEAF_KIND_SHIFT, -1 = none); a longer leaf sets prim[3] = LEAF_INDIRECT and names
+//                 leaf_tagged[prim[0] .. prim[0] + prim[1]).
+struct alignas(128) DWide {
+  float lo[4][3];
+  float hi[4][3];
+  int32_t child[4];
+  uint32_t order;
+  uint32_t pad[3];
+};
+static_assert(sizeof(DWide) == 128, "DWide must be one 128-byte line");
+struct alignas(64) DLeaf {
+  double bmin[3];
+  double bmax[3];
+  int32_t prim[4];
+};
+static_assert(sizeof(DLeaf) == 64, "DLeaf must be 64 bytes");
+#define WIDE_NONE INT32_MIN
+#define LEAF_INDIRECT (INT32_MIN + 1)
+#define WIDE_STACK_DEEP 36  // per-lane stack entries beyond those in LDS (three per wide level at most)
 #define WALK_STACK 24  // entries of the ordered walk's per-lane stack: the tree may be this deep at most
 
 struct alignas(64) DPrim {
@@ -74,6 +104,9 @@ struct DTexture {
 struct DScene {
   const DNode *nodes;
   const int32_t *leaf_prims;
+  const int32_t *leaf_tagged;  // leaf_prims[i] | kind << LEAF_KIND_SHIFT
+  const DWide *wide;           // the wide walk's nodes (root: 0) and leaves
+  const DLeaf *leaves;
   const DPrim *prims;
   const DMotion *motion;
   const mirt_material *materials;
@@ -213,7 +246,7 @@ struct RaysArgs {
 };
 
 // Launchers defined in kernels.hip (the only translation unit compiled for the GPU).
-// walk: WALK_* (wave-coherent, per lane in the reference's order, per lane nearer child first);
+// walk: WALK_* (wave-coherent, per lane in the reference's order, per lane nearer child first, 4-wide and batched);
 // uv: the scene samples image maps, so hits carry texture coordinates and a tangent frame;
 // motion: some ray of the launch may be at a shutter time other than 0.5.
 void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);

@@ -255,8 +255,8 @@ DEV void isect_sphere(const X &xf, const RayL &ray, double t_min, double &closes
 }
 
 // ---- cube (Cube.cpp:10-145): the box [-1,1]^3 ----------------------------------------------------
-template <bool SHADOW, bool UV, class X>
-DEV void isect_cube(const X &xf, ro_doubles scale, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+template <bool SHADOW, bool UV, class X, class P>
+DEV void isect_cube(const X &xf, P scale, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                     int prim) {
   const d3 o = xf.obj_point(ray.o), d = xf.obj_dir(ray.d);
   double t_near = t_min, t_far = closest_t;
@@ -319,10 +319,13 @@ DEV void plane_frame(Best<true> &b, ro_doubles pl, d3 ip) {
   b.set_uv(dot(local, e1) / pl[15], dot(local, e2) / pl[19]);
   b.set_tan(e1);
 }
-template <bool SHADOW, bool UV>
-DEV void isect_plane(ro_doubles pl, int flags, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+// pv: the first twelve values of the record (point, normal, bounds), wherever the caller holds them;
+// pl: the record itself, read for the edge frame of a hit when texture coordinates are wanted
+template <bool SHADOW, bool UV, class P>
+DEV void isect_plane(P pv, ro_doubles pl, int flags, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                      int prim) {
-  const d3 p0 = ld3(pl), n = ld3(pl + 3), lo = ld3(pl + 6), hi = ld3(pl + 9);
+  const d3 p0 = mk(pv[0], pv[1], pv[2]), n = mk(pv[3], pv[4], pv[5]), lo = mk(pv[6], pv[7], pv[8]),
+           hi = mk(pv[9], pv[10], pv[11]);
   const double denom = dot(n, ray.d);
   if (same(denom, 0.0)) return;
   const double t = dot(p0 - ray.o, n) / denom;
@@ -481,8 +484,8 @@ DEV int quartic_roots(const double *c, double *s) {  // c[0] + ... + c[4] x^4  (
   return n;
 }
 
-template <bool SHADOW, bool UV, class X>
-DEV void isect_torus(const X &xf, ro_doubles prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+template <bool SHADOW, bool UV, class X, class P>
+DEV void isect_torus(const X &xf, P prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                      int prim) {
   const d3 o = xf.obj_point(ray.o);
   d3 d = xf.obj_dir(ray.d);
@@ -567,8 +570,8 @@ DEV void isect_torus(const X &xf, ro_doubles prm, const RayL &ray, double t_min,
 }
 
 // ---- cylinder (Cylinder.cpp:7-116): side + both caps, strict `<` against the nearest so far --------
-template <bool SHADOW, bool UV, class X>
-DEV void isect_cylinder(const X &xf, ro_doubles prm, const RayL &ray, double t_min, double &closest_t,
+template <bool SHADOW, bool UV, class X, class P>
+DEV void isect_cylinder(const X &xf, P prm, const RayL &ray, double t_min, double &closest_t,
                         Best<UV> &b, int prim) {
   const d3 o = xf.obj_point(ray.o), d = xf.obj_dir(ray.d);
   const double radius = prm[0], depth = prm[1], hd = depth / 2.0;
@@ -641,8 +644,8 @@ DEV void isect_cylinder(const X &xf, ro_doubles prm, const RayL &ray, double t_m
 }
 
 // ---- cone (Cone.cpp:13-171): apex at +depth/2, base cap at -depth/2 -------------------------------
-template <bool SHADOW, bool UV, class X>
-DEV void isect_cone(const X &xf, ro_doubles prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+template <bool SHADOW, bool UV, class X, class P>
+DEV void isect_cone(const X &xf, P prm, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                     int prim) {
   const double EPS = 1e-6;
   const d3 o = xf.obj_point(ray.o), d = xf.obj_dir(ray.d);
@@ -754,15 +757,15 @@ DEV void isect_cone(const X &xf, ro_doubles prm, const RayL &ray, double t_min, 
 }
 
 // One primitive against one ray, with the transform kind chosen by the (wave-uniform) record.
-template <bool SHADOW, bool UV, bool MOTION, class X>
-DEV void isect_shape(const RO DPrim &pr, const X &xf, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
+template <bool SHADOW, bool UV, bool MOTION, class X, class P>
+DEV void isect_shape(int type, P param, const X &xf, const RayL &ray, double t_min, double &closest_t, Best<UV> &b,
                      int prim) {
-  switch (pr.type) {
+  switch (type) {
     case MIRT_SPHERE: isect_sphere<SHADOW, UV>(xf, ray, t_min, closest_t, b, prim); break;
-    case MIRT_CUBE: isect_cube<SHADOW, UV>(xf, pr.param, ray, t_min, closest_t, b, prim); break;
-    case MIRT_TORUS: isect_torus<SHADOW, UV>(xf, pr.param, ray, t_min, closest_t, b, prim); break;
-    case MIRT_CYLINDER: isect_cylinder<SHADOW, UV>(xf, pr.param, ray, t_min, closest_t, b, prim); break;
-    case MIRT_CONE: isect_cone<SHADOW, UV>(xf, pr.param, ray, t_min, closest_t, b, prim); break;
+    case MIRT_CUBE: isect_cube<SHADOW, UV>(xf, param, ray, t_min, closest_t, b, prim); break;
+    case MIRT_TORUS: isect_torus<SHADOW, UV>(xf, param, ray, t_min, closest_t, b, prim); break;
+    case MIRT_CYLINDER: isect_cylinder<SHADOW, UV>(xf, param, ray, t_min, closest_t, b, prim); break;
+    case MIRT_CONE: isect_cone<SHADOW, UV>(xf, param, ray, t_min, closest_t, b, prim); break;
     default: break;
   }
 }
@@ -774,7 +777,7 @@ DEV void isect_prim(const DScene &sc, const RO DPrim &pr, int prim, const RayL &
                     Best<UV> &b) {
   if (!pr.visible) return;
   if (pr.type == MIRT_PLANE) {
-    isect_plane<SHADOW, UV>(pr.xf, pr.plane_flags, ray, t_min, closest_t, b, prim);
+    isect_plane<SHADOW, UV>((ro_doubles)pr.xf, pr.xf, pr.plane_flags, ray, t_min, closest_t, b, prim);
     return;
   }
   if (MOTION && pr.motion != MOTION_NONE) {
@@ -784,14 +787,85 @@ DEV void isect_prim(const DScene &sc, const RO DPrim &pr, int prim, const RayL &
       xf.m = mo.m;
       const double t = ray.time;
       xf.t = mk(mo.t0[0] + mo.dt[0] * t, mo.t0[1] + mo.dt[1] * t, mo.t0[2] + mo.dt[2] * t);
-      isect_shape<SHADOW, UV, MOTION>(pr, xf, ray, t_min, closest_t, b, prim);
+      isect_shape<SHADOW, UV, MOTION>(pr.type, (ro_doubles)pr.param, xf, ray, t_min, closest_t, b, prim);
     } else {
       const XfG xf = motion_general(mo, ray.time);
-      isect_shape<SHADOW, UV, MOTION>(pr, xf, ray, t_min, closest_t, b, prim);
+      isect_shape<SHADOW, UV, MOTION>(pr.type, (ro_doubles)pr.param, xf, ray, t_min, closest_t, b, prim);
     }
     return;
   }
   XfS xf;
   xf.m = pr.xf;
-  isect_shape<SHADOW, UV, MOTION>(pr, xf, ray, t_min, closest_t, b, prim);
+  isect_shape<SHADOW, UV, MOTION>(pr.type, (ro_doubles)pr.param, xf, ray, t_min, closest_t, b, prim);
+}
+
+// The same for the per-lane walks, where every lane holds a different primitive and a record
+// field read where it is first needed is a round trip to memory of its own (flags, then kind, then
+// the map, then the parameters ...).  Here what every test needs -- the 32-byte header, the
+// world-to-object rows (planes: point, normal, bounds) and the parameters, 160 bytes -- is fetched
+// by ten loads issued together before anything is looked at; the object-to-world rows are read
+// only by a ray that hits.
+struct XfSV {
+  double m[12];  // world_to_object rows 0-2
+  ro_doubles w;  // object_to_world rows 0-2 (DPrim::xf + 12)
+  DEV d3 obj_point(d3 p) const {
+    return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+  }
+  DEV d3 obj_dir(d3 d) const {
+    return {m[0] * d.x + m[1] * d.y + m[2] * d.z, m[4] * d.x + m[5] * d.y + m[6] * d.z,
+            m[8] * d.x + m[9] * d.y + m[10] * d.z};
+  }
+  DEV d3 world_point(d3 p) const {
+    return {w[0] * p.x + w[1] * p.y + w[2] * p.z + w[3], w[4] * p.x + w[5] * p.y + w[6] * p.z + w[7],
+            w[8] * p.x + w[9] * p.y + w[10] * p.z + w[11]};
+  }
+  DEV d3 world_dir(d3 d) const {
+    return {w[0] * d.x + w[1] * d.y + w[2] * d.z, w[4] * d.x + w[5] * d.y + w[6] * d.z,
+            w[8] * d.x + w[9] * d.y + w[10] * d.z};
+  }
+  DEV d3 world_normal(d3 n) const {
+    return {m[0] * n.x + m[4] * n.y + m[8] * n.z, m[1] * n.x + m[5] * n.y + m[9] * n.z,
+            m[2] * n.x + m[6] * n.y + m[10] * n.z};
+  }
+};
+typedef double gdbl2 __attribute__((ext_vector_type(2)));
+typedef int gint4 __attribute__((ext_vector_type(4)));
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void isect_prim_lane(const DScene &sc, const DPrim *pr, int prim, const RayL &ray, double t_min,
+                         double &closest_t, Best<UV> &b) {
+  const gint4 *hq = reinterpret_cast<const gint4 *>(pr);
+  gint4 h0 = hq[0], h1 = hq[1];  // type, visible, motion, material | motion_index, plane_flags, -, -
+  const gdbl2 *xq = reinterpret_cast<const gdbl2 *>(pr->xf);
+  gdbl2 x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3], x4 = xq[4], x5 = xq[5];
+  const gdbl2 *pq = reinterpret_cast<const gdbl2 *>(pr->param);
+  gdbl2 p0 = pq[0], p1 = pq[1];
+  // everything has to have arrived here: keeps the loads above from being moved behind the branches below
+  asm volatile("" : "+v"(h0), "+v"(h1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(p0), "+v"(p1));
+  if (!h0.y) return;
+  const double xv[12] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y, x4.x, x4.y, x5.x, x5.y};
+  if (h0.x == MIRT_PLANE) {
+    isect_plane<SHADOW, UV>(xv, rdonly(pr)->xf, h1.y, ray, t_min, closest_t, b, prim);
+    return;
+  }
+  const double param[4] = {p0.x, p0.y, p1.x, p1.y};
+  if (MOTION && h0.z != MOTION_NONE) {
+    const RO DMotion &mo = rdonly(sc.motion)[h1.x];
+    if (h0.z == MOTION_TRANSLATE) {
+      XfT xf;
+      xf.m = mo.m;
+      const double t = ray.time;
+      xf.t = mk(mo.t0[0] + mo.dt[0] * t, mo.t0[1] + mo.dt[1] * t, mo.t0[2] + mo.dt[2] * t);
+      isect_shape<SHADOW, UV, MOTION>(h0.x, param, xf, ray, t_min, closest_t, b, prim);
+    } else {
+      const XfG xf = motion_general(mo, ray.time);
+      isect_shape<SHADOW, UV, MOTION>(h0.x, param, xf, ray, t_min, closest_t, b, prim);
+    }
+    return;
+  }
+  XfSV xf;
+#pragma unroll
+  for (int i = 0; i < 12; i++) xf.m[i] = xv[i];
+  xf.w = rdonly(pr)->xf + 12;
+  isect_shape<SHADOW, UV, MOTION>(h0.x, param, xf, ray, t_min, closest_t, b, prim);
 }

@@ -24,26 +24,48 @@ static void launch_trace_w(bool primary, bool uv, bool motion, unsigned grid, hi
   }
 }
 
-// Dispatch on the walk: WALK_PACKET, WALK_LANE, anything else WALK_ORDERED.
-#define BY_WALK(walk, call_packet, call_lane, call_ordered) \
-  do {                                                       \
-    if ((walk) == WALK_PACKET) call_packet;                  \
-    else if ((walk) == WALK_LANE) call_lane;                 \
-    else call_ordered;                                       \
+// Dispatch on the walk.  MIRT_WALKS (development aid) is a bit mask of the walks to compile, bit = WALK_*;
+// a walk left out falls back to the per-lane walk in the reference's order.
+#ifndef MIRT_WALKS
+#define MIRT_WALKS 15
+#endif
+#if MIRT_WALKS & 1
+#define IF_PACKET(...) __VA_ARGS__
+#else
+#define IF_PACKET(...) (void)0
+#endif
+#if MIRT_WALKS & 4
+#define IF_ORDERED(...) __VA_ARGS__
+#else
+#define IF_ORDERED(...) (void)0
+#endif
+#if MIRT_WALKS & 8
+#define IF_WIDE(...) __VA_ARGS__
+#else
+#define IF_WIDE(...) (void)0
+#endif
+#define BY_WALK(walk, call_packet, call_lane, call_ordered, call_wide)             \
+  do {                                                                             \
+    if ((walk) == WALK_PACKET && (MIRT_WALKS & 1)) IF_PACKET(call_packet);         \
+    else if ((walk) == WALK_ORDERED && (MIRT_WALKS & 4)) IF_ORDERED(call_ordered); \
+    else if ((walk) == WALK_WIDE && (MIRT_WALKS & 8)) IF_WIDE(call_wide);          \
+    else call_lane;                                                                \
   } while (0)
 
 void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   BY_WALK(walk, launch_trace_w<WALK_PACKET>(primary, uv, motion, grid, st, a),
           launch_trace_w<WALK_LANE>(primary, uv, motion, grid, st, a),
-          launch_trace_w<WALK_ORDERED>(primary, uv, motion, grid, st, a));
+          launch_trace_w<WALK_ORDERED>(primary, uv, motion, grid, st, a),
+          launch_trace_w<WALK_WIDE>(primary, uv, motion, grid, st, a));
 }
 
 void launch_shadow(int walk, unsigned grid, void *stream, const ShadowArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   BY_WALK(walk, hipLaunchKernelGGL(k_shadow<WALK_PACKET>, dim3(grid), dim3(256), 0, st, a),
           hipLaunchKernelGGL(k_shadow<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
-          hipLaunchKernelGGL(k_shadow<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a));
+          hipLaunchKernelGGL(k_shadow<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_shadow<WALK_WIDE>, dim3(grid), dim3(256), 0, st, a));
 }
 
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a) {
@@ -54,14 +76,16 @@ void launch_trace_ids(int walk, unsigned grid, void *stream, const IdsArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   BY_WALK(walk, hipLaunchKernelGGL(k_trace_ids<WALK_PACKET>, dim3(grid), dim3(256), 0, st, a),
           hipLaunchKernelGGL(k_trace_ids<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
-          hipLaunchKernelGGL(k_trace_ids<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a));
+          hipLaunchKernelGGL(k_trace_ids<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_trace_ids<WALK_WIDE>, dim3(grid), dim3(256), 0, st, a));
 }
 
 void launch_trace_rays(int walk, unsigned grid, void *stream, const RaysArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   BY_WALK(walk, hipLaunchKernelGGL(k_trace_rays<WALK_PACKET>, dim3(grid), dim3(256), 0, st, a),
           hipLaunchKernelGGL(k_trace_rays<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
-          hipLaunchKernelGGL(k_trace_rays<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a));
+          hipLaunchKernelGGL(k_trace_rays<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL(k_trace_rays<WALK_WIDE>, dim3(grid), dim3(256), 0, st, a));
 }
 
 // ---- working memory for the entry point that allocates nothing ----------------------------------

@@ -44,7 +44,12 @@
 #define MIRT_LANE_WALK_WAVES 4
 #endif
 #define WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#define WAVES_FOR_WALK(walk, packet_waves) WAVES_PER_SIMD((walk) == WALK_PACKET ? (packet_waves) : MIRT_LANE_WALK_WAVES)
+#ifndef MIRT_WIDE_WALK_WAVES
+#define MIRT_WIDE_WALK_WAVES 3
+#endif
+#define WAVES_FOR_WALK(walk, packet_waves)                                                   \
+  WAVES_PER_SIMD((walk) == WALK_PACKET ? (packet_waves) : (walk) == WALK_ORDERED ? 3 : (walk) == WALK_WIDE \
+                     ? MIRT_WIDE_WALK_WAVES : MIRT_LANE_WALK_WAVES)
 // Keeps the compiler from carrying values in registers across a section whose register budget is
 // tight: what is stored to LDS before the fence has to be loaded again after the next one.
 #define PARK_FENCE() asm volatile("" ::: "memory")
@@ -95,6 +100,46 @@ DEV bool box_hit(const RO DNode &n, const RayL &r, double t_min, double t_max) {
     if (t_max <= t_min) return false;
   }
   return true;
+}
+
+// A node as the per-lane walks read it: the whole 64-byte record in four 16-byte loads issued
+// together, and a box test without early exits, so that nothing of the record is fetched behind a
+// branch.  (Read field by field inside the early-exit test, a node costs four to five dependent
+// round trips to memory per step -- x slabs, y slabs, z slabs, then the links -- which is what the
+// per-lane walks were bound by: about 3000 cycles a step on a million primitives.)
+struct NodeVal {
+  double b[6];  // bmin, bmax
+  int32_t skip, first, count, order;
+};
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef float flt4v __attribute__((ext_vector_type(4)));
+DEV NodeVal load_node(const DNode *p) {
+  const dbl2 *q = reinterpret_cast<const dbl2 *>(p);
+  const dbl2 a = q[0], b = q[1], c = q[2];
+  const int4v m = reinterpret_cast<const int4v *>(p)[3];
+  NodeVal n;
+  n.b[0] = a.x; n.b[1] = a.y; n.b[2] = b.x; n.b[3] = b.y; n.b[4] = c.x; n.b[5] = c.y;
+  n.skip = m.x; n.first = m.y; n.count = m.z; n.order = m.w;
+  return n;
+}
+// BoundingBox::intersect (BoundingBox.h:14-31) on values already in registers.  The reference
+// returns at the first axis that fails; carrying on and remembering the failure gives the same
+// answer (the bounds up to the first failure are the same).
+DEV bool box_hit_v(const double *lo, const double *hi, const RayL &r, double t_min, double t_max) {
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const double inv = comp(r.inv, a), o = comp(r.o, a);
+    double t0 = (lo[a] - o) * inv;
+    double t1 = (hi[a] - o) * inv;
+    const bool neg = inv < 0.0;
+    const double n0 = neg ? t1 : t0, n1 = neg ? t0 : t1;
+    t_min = maxd(n0, t_min);
+    t_max = mind(n1, t_max);
+    ok = ok & !(t_max <= t_min);
+  }
+  return ok;
 }
 
 // intersect_bvh (Bvh.cpp:306-333) for the 64 rays of a wave at once.  Must be called by all lanes
@@ -164,19 +209,15 @@ DEV void traverse_lane(const DScene &sc, const RayL &ray, bool active, double t_
       if (n_walking == 0) break;
       if (n_walking <= LANE_FEW_WALKERS && __popcll(__ballot(count > 0)) >= LANE_MANY_PENDING) break;
       if (walking) {
-        const RO DNode &nd = rdonly(sc.nodes)[node];
+        const NodeVal nd = load_node(sc.nodes + node);
         n_node++;
-        if (box_hit(nd, ray, t_min, closest_t)) {
-          if (nd.first >= 0) {
-            first = nd.first;
-            count = nd.count;
-            node = nd.skip;
-          } else {
-            node = node + 1;
-          }
-        } else {
-          node = nd.skip;
+        const bool hit = box_hit_v(nd.b, nd.b + 3, ray, t_min, closest_t);
+        const bool leaf = nd.first >= 0;
+        if (hit && leaf) {
+          first = nd.first;
+          count = nd.count;
         }
+        node = (hit && !leaf) ? node + 1 : nd.skip;
       }
     }
     // Drain: every lane that holds a leaf intersects its primitives, in leaf order.
@@ -184,7 +225,7 @@ DEV void traverse_lane(const DScene &sc, const RayL &ray, bool active, double t_
       if (k < count) {
         const int pi = rdonly(sc.leaf_prims)[first + k];
         n_prim++;
-        isect_prim<SHADOW, UV, MOTION>(sc, rdonly(sc.prims)[pi], pi, ray, t_min, closest_t, best);
+        isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
       }
     }
     count = 0;
@@ -208,10 +249,10 @@ DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double
   while (__any(node >= 0)) {
     int first = 0, count = 0;
     while (node >= 0 && count == 0) {
-      const RO DNode &nd = rdonly(sc.nodes)[node];
+      const NodeVal nd = load_node(sc.nodes + node);
       n_node++;
       int next = -1;
-      if (box_hit(nd, ray, t_min, closest_t)) {
+      if (box_hit_v(nd.b, nd.b + 3, ray, t_min, closest_t)) {
         if (nd.first >= 0) {
           first = nd.first;
           count = nd.count;
@@ -231,20 +272,171 @@ DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double
       if (k < count) {
         const int pi = rdonly(sc.leaf_prims)[first + k];
         n_prim++;
-        isect_prim<SHADOW, UV, MOTION>(sc, rdonly(sc.prims)[pi], pi, ray, t_min, closest_t, best);
+        isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
       }
     }
   }
 }
 
-// WALK: WALK_PACKET (small scenes, coherent rays), WALK_LANE (per lane, the reference's order) or
-// WALK_ORDERED (per lane, nearer child first).
+// The throughput walk for large scenes.  Measured on a million primitives, the walks above spend
+// three quarters of their time walking, about 3000 cycles per step: every node test is a dependent
+// fetch from a 128 MB node array, and 23 % of the lanes are busy in a step (the others hold a leaf and
+// wait, or have finished).  This walk goes through the SAME tree, collapsed two levels at a time into
+// 4-wide nodes (one 128-byte line: the four grandchildren's boxes rounded outwards to float, so a
+// fetch brings four tests and half the levels disappear), visits the children nearer-first in the
+// order the binary ordered walk would, and batches the primitive tests by kind:
+//  * a collapsed inner node's own box is never tested.  It contains its children's boxes, so a ray that
+//    enters a child's box also enters it: leaving it out changes no result.  The float boxes are
+//    supersets tested in double (rounding is monotone, so a superset box passes whenever the exact one
+//    does); a leaf's exact double box is then tested as the reference tests it, including the rule
+//    that a box of zero thickness is never hit (BoundingBox.h:27);
+//  * a lane that enters a leaf only notes the leaf's primitives in a small per-lane list in LDS and
+//    walks on; when too few lanes can still walk, the wave picks the kind most lanes hold and every
+//    lane holding one tests one primitive of that kind -- one intersector, many lanes.
+// A primitive is tested against the closest hit known when its turn comes, so the closest hit is the
+// same as in the other walks; the order of the tests differs (exact ties may resolve differently, as
+// in the ordered walk), and boxes are tested against a closest hit that may be a little out of date.
+#ifndef PEND_SLOTS
+#define PEND_SLOTS 8  // primitives a lane can hold untested (at most 8: one byte of slot mask per kind)
+#endif
+#ifndef WIDE_WALK_MIN
+#define WIDE_WALK_MIN 16  // walk on while at least this many lanes can, else test a batch
+#endif
+#ifndef WIDE_STACK_LDS
+#define WIDE_STACK_LDS 12  // stack entries per lane kept in LDS; deeper ones go to the lane's private memory
+#endif
+
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void traverse_wide(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
+                       Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
+  __shared__ int32_t stack_lds[WIDE_STACK_LDS][256];
+  __shared__ int32_t pend[PEND_SLOTS][256];
+  int32_t stack_deep[WIDE_STACK_DEEP];  // private memory; touched only by lanes whose stack outgrows LDS
+  const int tid = threadIdx.x;
+  int sp = 0;
+  auto push = [&](int32_t v) {
+    if (sp < WIDE_STACK_LDS) stack_lds[sp][tid] = v;
+    else stack_deep[sp - WIDE_STACK_LDS] = v;
+    sp++;
+  };
+  auto pop = [&]() {
+    sp--;
+    return sp < WIDE_STACK_LDS ? stack_lds[sp][tid] : stack_deep[sp - WIDE_STACK_LDS];
+  };
+  int32_t cur = active ? 0 : WIDE_NONE;  // >= 0: wide node; < 0: ~leaf; WIDE_NONE: nothing left
+  uint32_t used = 0;          // bit s: slot s of this lane's list holds a primitive
+  unsigned long long km = 0;  // bits [8k, 8k + 8): the slots that hold a primitive of kind k
+  // the sign of the ray direction per axis, as the ordered walk reads it
+  const uint32_t up = (ray.d.x >= 0.0 ? 1u : 0u) | (ray.d.y >= 0.0 ? 2u : 0u) | (ray.d.z >= 0.0 ? 4u : 0u);
+  for (;;) {
+    const int room = PEND_SLOTS - __popc(used);
+    const bool walks = cur != WIDE_NONE && room >= 2;
+    const int n_walk = __popcll(__ballot(walks));
+    const bool pending = __any(used != 0);
+    if (n_walk == 0 && !pending) break;  // a lane with a node always has room once nothing is pending
+    if (n_walk >= WIDE_WALK_MIN || !pending) {
+      if (walks) {
+        if (cur >= 0) {
+          // the whole 128-byte record in eight loads issued together
+          const flt4v *wq = reinterpret_cast<const flt4v *>(sc.wide + cur);
+          const flt4v f0 = wq[0], f1 = wq[1], f2 = wq[2], f3 = wq[3], f4 = wq[4], f5 = wq[5];
+          const int4v child = reinterpret_cast<const int4v *>(wq)[6];
+          const uint32_t order = reinterpret_cast<const uint32_t *>(wq)[28];
+          const float flo[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+          const float fhi[12] = {f3.x, f3.y, f3.z, f3.w, f4.x, f4.y, f4.z, f4.w, f5.x, f5.y, f5.z, f5.w};
+          auto kid = [&](int i) { return i == 0 ? child.x : i == 1 ? child.y : i == 2 ? child.z : child.w; };
+          n_node += 4;
+          uint32_t hit = 0;
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const double lo[3] = {(double)flo[3 * c], (double)flo[3 * c + 1], (double)flo[3 * c + 2]};
+            const double hi[3] = {(double)fhi[3 * c], (double)fhi[3 * c + 1], (double)fhi[3 * c + 2]};
+            if (box_hit_v(lo, hi, ray, t_min, closest_t)) hit |= 1u << c;
+          }
+          // Visiting order of the binary ordered walk: the top node's two children, nearer first,
+          // and within each its own two children, nearer first.  order: 3 bits per binary node
+          // (top, first child, second child): axis, and bit 2 = the second child is the lower one.
+          const uint32_t o = order;
+          const bool t2 = (((o >> 2) & 1u) != 0) == (((up >> (o & 3u)) & 1u) != 0);
+          const bool a2 = (((o >> 5) & 1u) != 0) == (((up >> ((o >> 3) & 3u)) & 1u) != 0);
+          const bool b2 = (((o >> 8) & 1u) != 0) == (((up >> ((o >> 6) & 3u)) & 1u) != 0);
+          const int an = a2 ? 1 : 0, bn = b2 ? 3 : 2;  // the nearer slot of each pair
+          const int s0 = t2 ? bn : an, s1 = s0 ^ 1, s2 = t2 ? an : bn, s3 = s2 ^ 1;
+          // farthest first onto the stack, so that the nearest comes off first
+          if (hit & (1u << s3)) push(kid(s3));
+          if (hit & (1u << s2)) push(kid(s2));
+          if (hit & (1u << s1)) push(kid(s1));
+          if (hit & (1u << s0)) push(kid(s0));
+        } else {
+          const dbl2 *lq = reinterpret_cast<const dbl2 *>(sc.leaves + ~cur);
+          const dbl2 l0 = lq[0], l1 = lq[1], l2 = lq[2];
+          const int4v lp = reinterpret_cast<const int4v *>(lq)[3];
+          const double lb[6] = {l0.x, l0.y, l1.x, l1.y, l2.x, l2.y};
+          auto lprim = [&](int i) { return i == 0 ? lp.x : i == 1 ? lp.y : i == 2 ? lp.z : lp.w; };
+          n_node++;
+          if (box_hit_v(lb, lb + 3, ray, t_min, closest_t)) {
+            if (lp.w != LEAF_INDIRECT && (room >= 4 || (room == 2 ? lp.z : lp.w) < 0)) {  // room >= 2 here
+              // up to four primitives named in the record, and room for them
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const int tag = lprim(k);
+                if (tag >= 0) {
+                  const int slot = __ffs(~used) - 1;
+                  pend[slot][tid] = tag & LEAF_PRIM_MASK;
+                  used |= 1u << slot;
+                  km |= (1ull << slot) << (8 * (tag >> LEAF_KIND_SHIFT));
+                }
+              }
+            } else {
+              // no room for them all, or a leaf of more than four (trees cut off at the depth limit): test here
+              const bool indirect = lp.w == LEAF_INDIRECT;
+              const int n = indirect ? lp.y : 4;
+              for (int k = 0; k < n; k++) {
+                const int tag = indirect ? rdonly(sc.leaf_tagged)[lp.x + k] : lprim(k);
+                if (tag >= 0) {
+                  const int pi = tag & LEAF_PRIM_MASK;
+                  n_prim++;
+                  isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+                }
+              }
+            }
+          }
+        }
+        cur = sp > 0 ? pop() : WIDE_NONE;
+      }
+      continue;
+    }
+    // too few lanes can walk: test a batch of the kind most lanes hold
+    int kind = 0, most = -1;
+#pragma unroll
+    for (int k = 0; k <= MIRT_CONE; k++) {
+      const int c = __popcll(__ballot(((km >> (8 * k)) & 0xffull) != 0));
+      if (c > most) {
+        most = c;
+        kind = k;
+      }
+    }
+    const uint32_t mine = (uint32_t)(km >> (8 * kind)) & 0xffu;
+    if (mine) {
+      const int slot = __ffs(mine) - 1;
+      const int pi = pend[slot][tid];
+      used &= ~(1u << slot);
+      km &= ~((1ull << slot) << (8 * kind));
+      n_prim++;
+      isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+    }
+  }
+}
+
+// WALK: WALK_PACKET (small scenes, coherent rays), WALK_LANE (per lane, the reference's order),
+// WALK_ORDERED (per lane, nearer child first) or WALK_WIDE (4-wide nodes, nearer first, tests batched by kind).
 template <int WALK, bool SHADOW, bool UV, bool MOTION>
 DEV void traverse(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t, Best<UV> &best,
                   unsigned &n_node, unsigned &n_prim) {
   if (WALK == WALK_PACKET) traverse_packet<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
   else if (WALK == WALK_LANE) traverse_lane<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
-  else traverse_ordered<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
+  else if (WALK == WALK_ORDERED) traverse_ordered<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
+  else traverse_wide<SHADOW, UV, MOTION>(sc, ray, active, t_min, closest_t, best, n_node, n_prim);
 }
 
 // What shading needs from a hit (HitRecord, HitRecord.h:8-32).

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 W, H = 96, 54  # size of the committed golden maps
 
 
-@pytest.mark.parametrize("traversal", ["packet", "lane", "ordered"])
+@pytest.mark.parametrize("traversal", ["packet", "lane", "ordered", "wide"])
 @pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
 def test_closest_hit_vs_golden_and_oracle(name, traversal, host_scenes, device_scenes):
     """Primitive id, distance, normal and uv of pixel-centre rays (mirt_trace_ids), with either BVH walk."""
@@ -48,15 +48,15 @@ def test_closest_hit_vs_golden_and_oracle(name, traversal, host_scenes, device_s
         assert np.allclose(got["uv"][sel], gold["uv"][sel], atol=tol)
 
 
-@pytest.mark.parametrize("traversal", ["packet", "lane", "ordered"])
+@pytest.mark.parametrize("traversal", ["packet", "lane", "ordered", "wide"])
 @pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
 def test_deterministic_render_vs_golden(name, traversal, host_scenes, device_scenes):
     """Pixel-centre, time 0.5, depth 5 trace() colours against the reference's own values."""
-    if traversal == "ordered" and name in ("Test4", "Test6"):
+    if traversal in ("ordered", "wide") and name in ("Test4", "Test6"):
         # these two scenes have coincident surfaces (a glass cylinder standing on the ground plane, ...):
         # which of two hits at exactly the same distance wins depends on the order of the tests, and
-        # the ordered walk -- chosen automatically only for scenes of more than 512 primitives -- does
-        # not keep the reference's order
+        # the walks that visit the nearer child first (never chosen automatically for scenes this
+        # small) do not keep the reference's order
         pytest.skip("exact ties are order dependent")
     hs, ds = host_scenes(name), device_scenes(name, traversal)
     cam, _ = hs.camera(0)
@@ -341,7 +341,7 @@ def test_million_primitive_cloud_vs_oracle(million):
     cam, _ = hs.camera(0)
     w, h = 192, 108
     ref = O.trace_ids(hs.desc, cam, w, h)
-    for walk in ("lane", "ordered", "auto"):
+    for walk in ("lane", "ordered", "wide", "auto"):
         ds.set_traversal(walk)
         got = ds.trace_ids(cam, w, h)
         same = got["prim_id"] == ref["prim_id"]
