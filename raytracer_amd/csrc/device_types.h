@@ -115,10 +115,10 @@ struct DScene {
   const DTexture *textures;
   int32_t n_nodes, n_prims, n_lights, n_textures;
   double background[3];  // background_color * background_strength (Raytracer.cpp:472)
+  int32_t kinds;         // bit k: some primitive is of kind k (MIRT_SPHERE ... MIRT_CONE)
   int32_t any_motion;    // some primitive has motion data
   int32_t any_maps;      // some material samples a texture, normal map or bump map
   int32_t max_children;  // most rays one hit can spawn, given the materials (and glossy_samples, added per frame)
-  int32_t pad;
 };
 
 // Camera with the basis of Camera::get_ray (Camera.cpp:32-58) evaluated once on the host.
@@ -183,6 +183,18 @@ struct alignas(16) DShadowItem {
 };
 static_assert(sizeof(DShadowItem) == 64, "DShadowItem must be 64 bytes");
 
+// Closest hit of one ray, as k_closest_stream leaves it for k_shade.
+struct alignas(16) DHit {
+  int32_t prim, pad;  // -1: no hit
+  double t;
+  double p[3], n[3];  // world hit point; outward world normal before normalisation (planes: unit)
+};
+static_assert(sizeof(DHit) == 64, "DHit must be 64 bytes");
+struct alignas(16) DHitUV {
+  double u, v, tan[3], pad;
+};
+static_assert(sizeof(DHitUV) == 48, "DHitUV must be 48 bytes");
+
 // Statistics counters, replicated COUNTER_SHARDS times (one 64-byte line each) for the same reason
 // as the queue tails; the host adds the replicas up after the frame.
 #define COUNTER_SHARDS 256
@@ -207,6 +219,9 @@ struct TraceArgs {
   DCounters *counters;       // COUNTER_SHARDS replicas
   uint32_t first;            // PRIMARY: first 16x16 block of this launch
   uint32_t n;                // PRIMARY: number of blocks
+  uint32_t *grab;            // k_closest_stream: the next ray number nobody has taken yet (zero at launch)
+  DHit *hits;                // k_closest_stream -> k_shade, one per ray number
+  DHitUV *hits_uv;
 };
 
 struct ShadowArgs {
@@ -218,6 +233,7 @@ struct ShadowArgs {
   uint32_t pad;
   double *accum;
   DCounters *counters;
+  uint32_t *grab;  // k_shadow_stream: the next item number nobody has taken yet (zero at launch)
 };
 
 struct ResolveArgs {
@@ -251,6 +267,10 @@ struct RaysArgs {
 // motion: some ray of the launch may be at a shutter time other than 0.5.
 void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
 void launch_shadow(int walk, unsigned grid, void *stream, const ShadowArgs &a);
+void launch_shadow_stream(unsigned grid, void *stream, const ShadowArgs &a);  // wide walk, resident grid
+// wide walk, two launches: closest hits by a resident grid, then shading with one lane per ray
+void launch_closest_stream(bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
+void launch_shade(bool primary, bool uv, unsigned grid, void *stream, const TraceArgs &a);
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a);
 void launch_trace_ids(int walk, unsigned grid, void *stream, const IdsArgs &a);
 void launch_trace_rays(int walk, unsigned grid, void *stream, const RaysArgs &a);

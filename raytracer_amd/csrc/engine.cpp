@@ -123,6 +123,8 @@ struct mirt_scene {
   hipEvent_t null_stream_mark = nullptr;  // orders the engine's own stream after the caller's null stream
   DScene d{};
   int wide_depth = 0;  // levels of the wide walk's tree below its root
+  unsigned resident_grid = 768;  // blocks of a launch whose waves stay and take work off a queue: 3 per CU
+  bool stream_kernels = true;
   DeviceBuffer nodes, leaf_prims, leaf_tagged, wide, leaves, prims, motion, materials, transparency, lights, textures, light_frame;
   std::vector<DeviceBuffer> texels;
   std::vector<mirt_light> host_lights;
@@ -133,6 +135,7 @@ struct mirt_scene {
     bool fixed = false;  // working memory is a carve-up of the per-GPU static array: nothing is ever allocated
     RayQueueMem queues[2];  // rays of even / odd depth: a depth reads one and appends to the other
     DeviceBuffer shadow_items, control, accum;  // control: statistics counters, then the queue tails
+    DeviceBuffer hits, hits_uv;  // closest hits between k_closest_stream and k_shade (large scenes only)
     char *pinned = nullptr;  // read-back of the control block
     size_t pinned_bytes = 0;
     size_t ray_shard_cap = 0, shadow_shard_cap = 0;  // entries per queue shard
@@ -634,6 +637,13 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   sc->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&sc->null_stream_mark, hipEventDisableTiming));
+  {
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    sc->resident_grid = (unsigned)env_size("MIRT_RESIDENT_BLOCKS", (size_t)std::max(cus, 1) * 3);
+    const char *st = std::getenv("MIRT_STREAM");
+    sc->stream_kernels = !(st && st[0] == '0');
+  }
 
   const mirt_scene_desc &s = *desc;
   std::vector<DNode> nodes(s.n_nodes);
@@ -757,6 +767,8 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   d.n_lights = s.n_lights;
   d.n_textures = s.n_textures;
   for (int k = 0; k < 3; ++k) d.background[k] = s.background_color[k] * s.background_strength;
+  d.kinds = 0;
+  for (int i = 0; i < s.n_prims; ++i) d.kinds |= 1 << s.prims[i].type;
   d.any_motion = motion.empty() ? 0 : 1;
   d.any_maps = any_maps ? 1 : 0;
   d.max_children = 0;
@@ -949,6 +961,16 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       (uint64_t)QUEUE_SHARDS * std::min(ws->shadow_shard_cap / (256 * (size_t)S), ws->ray_shard_cap / (size_t)256);
   const uint64_t per_launch = std::max<uint64_t>(1, fit / (uint64_t)spp / sc->split);
   const size_t chunks = total_blocks ? (size_t)((total_blocks + per_launch - 1) / per_launch) : 0;
+  // Large scenes (wide walk): closest hits by a resident grid whose lanes take rays off a work counter,
+  // shading by a second launch; the hits of one launch wait in between.  Not with the static working
+  // memory, which has no room for them.
+  const bool streaming = sc->walk == WALK_WIDE && sc->stream_kernels && !ws->fixed;
+  if (streaming) {
+    const size_t most = std::max<size_t>((size_t)std::min<uint64_t>(per_launch, total_blocks) * (size_t)spp * 256,
+                                         levels > 1 ? ws->ray_shard_cap * QUEUE_SHARDS : 0);
+    HIP_TRY(ws->hits.reserve(std::max<size_t>(most, 1) * sizeof(DHit)));
+    if (uv) HIP_TRY(ws->hits_uv.reserve(std::max<size_t>(most, 1) * sizeof(DHitUV)));
+  }
   // tail counters: per primary launch and level, the rays and the shadow items that level queued
   const size_t stats_bytes = COUNTER_SHARDS * sizeof(DCounters);
   const size_t control_bytes = stats_bytes + chunks * (size_t)std::max(levels, 0) * 2 * kCountBytes;
@@ -1011,7 +1033,18 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
         HIP_TRY(hipEventRecord(t.a, stream));
       }
       const unsigned grid = depth == 0 ? nb * (unsigned)spp : consumer_grid;
-      launch_trace(sc->walk, depth == 0, uv, motion, grid, stream, a);
+      if (streaming) {
+        // a spare word of a tail block that this launch owns and nobody reads: the block of the rays it
+        // consumes (depth > 0), of the rays it appends (depth 0; appends touch words s * 64 only)
+        a.grab = depth > 0 ? tails(c, depth - 1, 0) + 2 : tails(c, 0, 0) + 3;
+        a.hits = ws->hits.as<DHit>();
+        a.hits_uv = ws->hits_uv.as<DHitUV>();
+        launch_closest_stream(depth == 0, uv, motion, sc->resident_grid, stream, a);
+        launch_shade(depth == 0, uv, grid, stream, a);
+        ws->launches++;
+      } else {
+        launch_trace(sc->walk, depth == 0, uv, motion, grid, stream, a);
+      }
       {
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess)
@@ -1037,7 +1070,12 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
         HIP_TRY(get_event(ws, ev_used, ts.b));
         HIP_TRY(hipEventRecord(ts.a, stream));
       }
-      launch_shadow(sc->walk, consumer_grid, stream, sa);
+      if (streaming) {
+        sa.grab = a.shadow_count + 1;  // a spare word of the launch's tail block, zeroed with it
+        launch_shadow_stream(sc->resident_grid, stream, sa);
+      } else {
+        launch_shadow(sc->walk, consumer_grid, stream, sa);
+      }
       HIP_TRY(hipGetLastError());
       if (kernel_timing) {
         HIP_TRY(hipEventRecord(ts.b, stream));

@@ -770,35 +770,6 @@ DEV void isect_shape(int type, P param, const X &xf, const RayL &ray, double t_m
   }
 }
 
-// intersect_obj (Bvh.cpp:244-304) for one ray.  MOTION = false compiles the kernels used when
-// every ray of the launch is at shutter time 0.5 (shadow rays, motion blur off).
-template <bool SHADOW, bool UV, bool MOTION>
-DEV void isect_prim(const DScene &sc, const RO DPrim &pr, int prim, const RayL &ray, double t_min, double &closest_t,
-                    Best<UV> &b) {
-  if (!pr.visible) return;
-  if (pr.type == MIRT_PLANE) {
-    isect_plane<SHADOW, UV>((ro_doubles)pr.xf, pr.xf, pr.plane_flags, ray, t_min, closest_t, b, prim);
-    return;
-  }
-  if (MOTION && pr.motion != MOTION_NONE) {
-    const RO DMotion &mo = rdonly(sc.motion)[pr.motion_index];
-    if (pr.motion == MOTION_TRANSLATE) {
-      XfT xf;
-      xf.m = mo.m;
-      const double t = ray.time;
-      xf.t = mk(mo.t0[0] + mo.dt[0] * t, mo.t0[1] + mo.dt[1] * t, mo.t0[2] + mo.dt[2] * t);
-      isect_shape<SHADOW, UV, MOTION>(pr.type, (ro_doubles)pr.param, xf, ray, t_min, closest_t, b, prim);
-    } else {
-      const XfG xf = motion_general(mo, ray.time);
-      isect_shape<SHADOW, UV, MOTION>(pr.type, (ro_doubles)pr.param, xf, ray, t_min, closest_t, b, prim);
-    }
-    return;
-  }
-  XfS xf;
-  xf.m = pr.xf;
-  isect_shape<SHADOW, UV, MOTION>(pr.type, (ro_doubles)pr.param, xf, ray, t_min, closest_t, b, prim);
-}
-
 // The same for the per-lane walks, where every lane holds a different primitive and a record
 // field read where it is first needed is a round trip to memory of its own (flags, then kind, then
 // the map, then the parameters ...).  Here what every test needs -- the 32-byte header, the
@@ -830,7 +801,46 @@ struct XfSV {
   }
 };
 typedef double gdbl2 __attribute__((ext_vector_type(2)));
+typedef double gdbl4 __attribute__((ext_vector_type(4)));
 typedef int gint4 __attribute__((ext_vector_type(4)));
+typedef int gint8 __attribute__((ext_vector_type(8)));
+
+// intersect_obj (Bvh.cpp:244-304) for one ray, on a record already fetched: header words (type,
+// visible, motion, material, motion_index, plane_flags), the first twelve values of DPrim::xf, the
+// parameters; `rec` is the record itself for what only a hit (or a moving primitive) reads.
+// MOTION = false compiles the kernels used when every ray of the launch is at shutter time 0.5
+// (shadow rays, motion blur off).
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void isect_fetched(const DScene &sc, int type, int visible, int motion, int motion_index, int plane_flags,
+                       const double *xv, const double *param, const RO DPrim *rec, int prim, const RayL &ray,
+                       double t_min, double &closest_t, Best<UV> &b) {
+  if (!visible) return;
+  if (type == MIRT_PLANE) {
+    isect_plane<SHADOW, UV>(xv, rec->xf, plane_flags, ray, t_min, closest_t, b, prim);
+    return;
+  }
+  if (MOTION && motion != MOTION_NONE) {
+    const RO DMotion &mo = rdonly(sc.motion)[motion_index];
+    if (motion == MOTION_TRANSLATE) {
+      XfT xf;
+      xf.m = mo.m;
+      const double t = ray.time;
+      xf.t = mk(mo.t0[0] + mo.dt[0] * t, mo.t0[1] + mo.dt[1] * t, mo.t0[2] + mo.dt[2] * t);
+      isect_shape<SHADOW, UV, MOTION>(type, param, xf, ray, t_min, closest_t, b, prim);
+    } else {
+      const XfG xf = motion_general(mo, ray.time);
+      isect_shape<SHADOW, UV, MOTION>(type, param, xf, ray, t_min, closest_t, b, prim);
+    }
+    return;
+  }
+  XfSV xf;
+#pragma unroll
+  for (int i = 0; i < 12; i++) xf.m[i] = xv[i];
+  xf.w = rec->xf + 12;
+  isect_shape<SHADOW, UV, MOTION>(type, param, xf, ray, t_min, closest_t, b, prim);
+}
+
+// Per-lane walks: every lane holds a different primitive; ten vector loads issued together.
 template <bool SHADOW, bool UV, bool MOTION>
 DEV void isect_prim_lane(const DScene &sc, const DPrim *pr, int prim, const RayL &ray, double t_min,
                          double &closest_t, Best<UV> &b) {
@@ -842,30 +852,23 @@ DEV void isect_prim_lane(const DScene &sc, const DPrim *pr, int prim, const RayL
   gdbl2 p0 = pq[0], p1 = pq[1];
   // everything has to have arrived here: keeps the loads above from being moved behind the branches below
   asm volatile("" : "+v"(h0), "+v"(h1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(p0), "+v"(p1));
-  if (!h0.y) return;
   const double xv[12] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y, x4.x, x4.y, x5.x, x5.y};
-  if (h0.x == MIRT_PLANE) {
-    isect_plane<SHADOW, UV>(xv, rdonly(pr)->xf, h1.y, ray, t_min, closest_t, b, prim);
-    return;
-  }
   const double param[4] = {p0.x, p0.y, p1.x, p1.y};
-  if (MOTION && h0.z != MOTION_NONE) {
-    const RO DMotion &mo = rdonly(sc.motion)[h1.x];
-    if (h0.z == MOTION_TRANSLATE) {
-      XfT xf;
-      xf.m = mo.m;
-      const double t = ray.time;
-      xf.t = mk(mo.t0[0] + mo.dt[0] * t, mo.t0[1] + mo.dt[1] * t, mo.t0[2] + mo.dt[2] * t);
-      isect_shape<SHADOW, UV, MOTION>(h0.x, param, xf, ray, t_min, closest_t, b, prim);
-    } else {
-      const XfG xf = motion_general(mo, ray.time);
-      isect_shape<SHADOW, UV, MOTION>(h0.x, param, xf, ray, t_min, closest_t, b, prim);
-    }
-    return;
-  }
-  XfSV xf;
-#pragma unroll
-  for (int i = 0; i < 12; i++) xf.m[i] = xv[i];
-  xf.w = rdonly(pr)->xf + 12;
-  isect_shape<SHADOW, UV, MOTION>(h0.x, param, xf, ray, t_min, closest_t, b, prim);
+  isect_fetched<SHADOW, UV, MOTION>(sc, h0.x, h0.y, h0.z, h1.x, h1.y, xv, param, rdonly(pr), prim, ray, t_min,
+                                    closest_t, b);
+}
+
+// Packet walk: the record's address is wave-uniform, so the same 160 bytes come through the scalar
+// data path -- five loads issued together, values in scalar registers.
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void isect_prim(const DScene &sc, const RO DPrim *pr, int prim, const RayL &ray, double t_min, double &closest_t,
+                    Best<UV> &b) {
+  gint8 h = *reinterpret_cast<const RO gint8 *>(pr);
+  const RO gdbl4 *xq = reinterpret_cast<const RO gdbl4 *>(pr->xf);
+  gdbl4 x0 = xq[0], x1 = xq[1], x2 = xq[2];
+  gdbl4 p0 = *reinterpret_cast<const RO gdbl4 *>(pr->param);
+  asm volatile("" : "+s"(h), "+s"(x0), "+s"(x1), "+s"(x2), "+s"(p0));
+  const double xv[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+  const double param[4] = {p0.x, p0.y, p0.z, p0.w};
+  isect_fetched<SHADOW, UV, MOTION>(sc, h.s0, h.s1, h.s2, h.s4, h.s5, xv, param, pr, prim, ray, t_min, closest_t, b);
 }

@@ -68,6 +68,36 @@ void launch_shadow(int walk, unsigned grid, void *stream, const ShadowArgs &a) {
           hipLaunchKernelGGL(k_shadow<WALK_WIDE>, dim3(grid), dim3(256), 0, st, a));
 }
 
+template <bool PRIMARY, bool UV, bool MOTION>
+static void launch_closest_stream_t(unsigned grid, hipStream_t st, const TraceArgs &a) {
+  hipLaunchKernelGGL((k_closest_stream<PRIMARY, UV, MOTION>), dim3(grid), dim3(256), 0, st, a);
+}
+void launch_closest_stream(bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int v = (primary ? 4 : 0) | (uv ? 2 : 0) | (motion ? 1 : 0);
+  switch (v) {
+    case 0: launch_closest_stream_t<false, false, false>(grid, st, a); break;
+    case 1: launch_closest_stream_t<false, false, true>(grid, st, a); break;
+    case 2: launch_closest_stream_t<false, true, false>(grid, st, a); break;
+    case 3: launch_closest_stream_t<false, true, true>(grid, st, a); break;
+    case 4: launch_closest_stream_t<true, false, false>(grid, st, a); break;
+    case 5: launch_closest_stream_t<true, false, true>(grid, st, a); break;
+    case 6: launch_closest_stream_t<true, true, false>(grid, st, a); break;
+    default: launch_closest_stream_t<true, true, true>(grid, st, a); break;
+  }
+}
+void launch_shade(bool primary, bool uv, unsigned grid, void *stream, const TraceArgs &a) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (primary && uv) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(256), 0, st, a);
+  else if (primary) hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(256), 0, st, a);
+  else if (uv) hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(256), 0, st, a);
+}
+
+void launch_shadow_stream(unsigned grid, void *stream, const ShadowArgs &a) {
+  hipLaunchKernelGGL(k_shadow_stream, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+}
+
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a) {
   hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
 }

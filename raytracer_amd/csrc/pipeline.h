@@ -83,25 +83,6 @@
 DEV double maxd(double a, double b) { return (a < b) ? b : a; }  // std::max(a, b)
 DEV double mind(double a, double b) { return (b < a) ? b : a; }  // std::min(a, b)
 
-// BoundingBox::intersect (BoundingBox.h:14-31), NaN behaviour of std::max / std::min included.
-DEV bool box_hit(const RO DNode &n, const RayL &r, double t_min, double t_max) {
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    const double inv = comp(r.inv, a), o = comp(r.o, a);
-    double t0 = (n.bmin[a] - o) * inv;
-    double t1 = (n.bmax[a] - o) * inv;
-    if (inv < 0.0) {
-      const double s = t0;
-      t0 = t1;
-      t1 = s;
-    }
-    t_min = maxd(t0, t_min);
-    t_max = mind(t1, t_max);
-    if (t_max <= t_min) return false;
-  }
-  return true;
-}
-
 // A node as the per-lane walks read it: the whole 64-byte record in four 16-byte loads issued
 // together, and a box test without early exits, so that nothing of the record is fetched behind a
 // branch.  (Read field by field inside the early-exit test, a node costs four to five dependent
@@ -113,6 +94,7 @@ struct NodeVal {
 };
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int16v __attribute__((ext_vector_type(16)));
 typedef float flt4v __attribute__((ext_vector_type(4)));
 DEV NodeVal load_node(const DNode *p) {
   const dbl2 *q = reinterpret_cast<const dbl2 *>(p);
@@ -123,8 +105,7 @@ DEV NodeVal load_node(const DNode *p) {
   n.skip = m.x; n.first = m.y; n.count = m.z; n.order = m.w;
   return n;
 }
-// BoundingBox::intersect (BoundingBox.h:14-31) on values already in registers.  The reference
-// returns at the first axis that fails; carrying on and remembering the failure gives the same
+// The same without branches, for the per-lane walks.  The reference returns at the first axis that fails; carrying on and remembering the failure gives the same
 // answer (the bounds up to the first failure are the same).
 DEV bool box_hit_v(const double *lo, const double *hi, const RayL &r, double t_min, double t_max) {
   bool ok = true;
@@ -142,6 +123,26 @@ DEV bool box_hit_v(const double *lo, const double *hi, const RayL &r, double t_m
   return ok;
 }
 
+// BoundingBox::intersect (BoundingBox.h:14-31) as written, NaN behaviour of std::max / std::min and the
+// early exits included, for values in scalar registers (packet walk).
+DEV bool box_hit_early(const double *lo, const double *hi, const RayL &r, double t_min, double t_max) {
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const double inv = comp(r.inv, a), o = comp(r.o, a);
+    double t0 = (lo[a] - o) * inv;
+    double t1 = (hi[a] - o) * inv;
+    if (inv < 0.0) {
+      const double s = t0;
+      t0 = t1;
+      t1 = s;
+    }
+    t_min = maxd(t0, t_min);
+    t_max = mind(t1, t_max);
+    if (t_max <= t_min) return false;
+  }
+  return true;
+}
+
 // intersect_bvh (Bvh.cpp:306-333) for the 64 rays of a wave at once.  Must be called by all lanes
 // of the wave; `active` masks the lanes that have a ray.
 template <bool SHADOW, bool UV, bool MOTION>
@@ -152,12 +153,16 @@ DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double 
   int node = 0;
   while (node < n_nodes) {
     const int un = __builtin_amdgcn_readfirstlane(node);
-    const RO DNode &nd = rdonly(sc.nodes)[un];
+    // the whole record in one scalar load: read field by field inside the box test it cost six
+    // dependent trips to the scalar cache per node (x, y, z slabs, then each link)
+    int16v raw = *reinterpret_cast<const RO int16v *>(rdonly(sc.nodes) + un);
+    asm volatile("" : "+s"(raw));
+    const NodeVal nd = __builtin_bit_cast(NodeVal, raw);
     const bool on = resume <= un;
     bool hit = false;
     if (on) {
       n_node++;
-      hit = box_hit(nd, ray, t_min, closest_t);
+      hit = box_hit_early(nd.b, nd.b + 3, ray, t_min, closest_t);
       if (!hit) resume = nd.skip;
     }
     if (!__any(hit)) {
@@ -167,10 +172,9 @@ DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double 
     if (nd.first >= 0) {
       for (int k = 0; k < nd.count; k++) {
         const int pi = rdonly(sc.leaf_prims)[nd.first + k];
-        const RO DPrim &pr = rdonly(sc.prims)[pi];
         if (hit) {
           n_prim++;
-          isect_prim<SHADOW, UV, MOTION>(sc, pr, pi, ray, t_min, closest_t, best);
+          isect_prim<SHADOW, UV, MOTION>(sc, rdonly(sc.prims) + pi, pi, ray, t_min, closest_t, best);
         }
       }
       node = nd.skip;
@@ -289,7 +293,9 @@ DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double
 //    enters a child's box also enters it: leaving it out changes no result.  The float boxes are
 //    supersets tested in double (rounding is monotone, so a superset box passes whenever the exact one
 //    does); a leaf's exact double box is then tested as the reference tests it, including the rule
-//    that a box of zero thickness is never hit (BoundingBox.h:27);
+//    that a box of zero thickness is never hit (BoundingBox.h:27).  (Tried: 256-byte nodes with exact
+//    boxes and the leaves' primitives in the slots -- no leaf visits, but twice the bytes and registers
+//    per visit: 14 % slower on a million primitives);
 //  * a lane that enters a leaf only notes the leaf's primitives in a small per-lane list in LDS and
 //    walks on; when too few lanes can still walk, the wave picks the kind most lanes hold and every
 //    lane holding one tests one primitive of that kind -- one intersector, many lanes.
@@ -302,129 +308,158 @@ DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double
 #ifndef WIDE_WALK_MIN
 #define WIDE_WALK_MIN 16  // walk on while at least this many lanes can, else test a batch
 #endif
+#ifndef WIDE_DRAIN_MIN
+#define WIDE_DRAIN_MIN 24  // test a batch as soon as this many lanes hold a primitive of one kind
+#endif
 #ifndef WIDE_STACK_LDS
 #define WIDE_STACK_LDS 12  // stack entries per lane kept in LDS; deeper ones go to the lane's private memory
 #endif
 
+// A lane's place in the wide walk.  The walk is written as one wave step at a time (wide_step) so that
+// a kernel can interleave steps with handing finished lanes their next ray.
+struct WideWalk {
+  int sp;
+  int32_t cur;            // >= 0: wide node; < 0: ~leaf; WIDE_NONE: nothing left to visit
+  uint32_t used;          // bit s: slot s of this lane's list holds a primitive
+  unsigned long long km;  // bits [8k, 8k + 8): the slots that hold a primitive of kind k
+  uint32_t up;            // the sign of the ray direction per axis, as the ordered walk reads it
+  DEV void start(const RayL &ray, bool active) {
+    sp = 0;
+    cur = active ? 0 : WIDE_NONE;
+    used = 0;
+    km = 0;
+    up = (ray.d.x >= 0.0 ? 1u : 0u) | (ray.d.y >= 0.0 ? 2u : 0u) | (ray.d.z >= 0.0 ? 4u : 0u);
+  }
+  DEV bool busy() const { return cur != WIDE_NONE || used != 0; }
+};
+
+// One step of the wave: the lanes that can walk visit their node or leaf, or -- when too few can --
+// the lanes holding a primitive of the most popular kind test it.  Returns false when no lane has
+// anything left.  Must be called by all lanes of the wave.
 template <bool SHADOW, bool UV, bool MOTION>
-DEV void traverse_wide(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
-                       Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
+DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &closest_t, Best<UV> &best, WideWalk &w,
+                   int32_t *deep, unsigned &n_node, unsigned &n_prim) {
   __shared__ int32_t stack_lds[WIDE_STACK_LDS][256];
   __shared__ int32_t pend[PEND_SLOTS][256];
-  int32_t stack_deep[WIDE_STACK_DEEP];  // private memory; touched only by lanes whose stack outgrows LDS
   const int tid = threadIdx.x;
-  int sp = 0;
   auto push = [&](int32_t v) {
-    if (sp < WIDE_STACK_LDS) stack_lds[sp][tid] = v;
-    else stack_deep[sp - WIDE_STACK_LDS] = v;
-    sp++;
+    if (w.sp < WIDE_STACK_LDS) stack_lds[w.sp][tid] = v;
+    else deep[w.sp - WIDE_STACK_LDS] = v;
+    w.sp++;
   };
   auto pop = [&]() {
-    sp--;
-    return sp < WIDE_STACK_LDS ? stack_lds[sp][tid] : stack_deep[sp - WIDE_STACK_LDS];
+    w.sp--;
+    return w.sp < WIDE_STACK_LDS ? stack_lds[w.sp][tid] : deep[w.sp - WIDE_STACK_LDS];
   };
-  int32_t cur = active ? 0 : WIDE_NONE;  // >= 0: wide node; < 0: ~leaf; WIDE_NONE: nothing left
-  uint32_t used = 0;          // bit s: slot s of this lane's list holds a primitive
-  unsigned long long km = 0;  // bits [8k, 8k + 8): the slots that hold a primitive of kind k
-  // the sign of the ray direction per axis, as the ordered walk reads it
-  const uint32_t up = (ray.d.x >= 0.0 ? 1u : 0u) | (ray.d.y >= 0.0 ? 2u : 0u) | (ray.d.z >= 0.0 ? 4u : 0u);
-  for (;;) {
-    const int room = PEND_SLOTS - __popc(used);
-    const bool walks = cur != WIDE_NONE && room >= 2;
-    const int n_walk = __popcll(__ballot(walks));
-    const bool pending = __any(used != 0);
-    if (n_walk == 0 && !pending) break;  // a lane with a node always has room once nothing is pending
-    if (n_walk >= WIDE_WALK_MIN || !pending) {
-      if (walks) {
-        if (cur >= 0) {
-          // the whole 128-byte record in eight loads issued together
-          const flt4v *wq = reinterpret_cast<const flt4v *>(sc.wide + cur);
-          const flt4v f0 = wq[0], f1 = wq[1], f2 = wq[2], f3 = wq[3], f4 = wq[4], f5 = wq[5];
-          const int4v child = reinterpret_cast<const int4v *>(wq)[6];
-          const uint32_t order = reinterpret_cast<const uint32_t *>(wq)[28];
-          const float flo[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-          const float fhi[12] = {f3.x, f3.y, f3.z, f3.w, f4.x, f4.y, f4.z, f4.w, f5.x, f5.y, f5.z, f5.w};
-          auto kid = [&](int i) { return i == 0 ? child.x : i == 1 ? child.y : i == 2 ? child.z : child.w; };
-          n_node += 4;
-          uint32_t hit = 0;
+  const int room = PEND_SLOTS - __popc(w.used);
+  const bool walks = w.cur != WIDE_NONE && room >= 2;
+  const int n_walk = __popcll(__ballot(walks));
+  // the kind of primitive most lanes hold, and how many lanes hold one
+  int kind = 0, most = 0;
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const double lo[3] = {(double)flo[3 * c], (double)flo[3 * c + 1], (double)flo[3 * c + 2]};
-            const double hi[3] = {(double)fhi[3 * c], (double)fhi[3 * c + 1], (double)fhi[3 * c + 2]};
-            if (box_hit_v(lo, hi, ray, t_min, closest_t)) hit |= 1u << c;
-          }
-          // Visiting order of the binary ordered walk: the top node's two children, nearer first,
-          // and within each its own two children, nearer first.  order: 3 bits per binary node
-          // (top, first child, second child): axis, and bit 2 = the second child is the lower one.
-          const uint32_t o = order;
-          const bool t2 = (((o >> 2) & 1u) != 0) == (((up >> (o & 3u)) & 1u) != 0);
-          const bool a2 = (((o >> 5) & 1u) != 0) == (((up >> ((o >> 3) & 3u)) & 1u) != 0);
-          const bool b2 = (((o >> 8) & 1u) != 0) == (((up >> ((o >> 6) & 3u)) & 1u) != 0);
-          const int an = a2 ? 1 : 0, bn = b2 ? 3 : 2;  // the nearer slot of each pair
-          const int s0 = t2 ? bn : an, s1 = s0 ^ 1, s2 = t2 ? an : bn, s3 = s2 ^ 1;
-          // farthest first onto the stack, so that the nearest comes off first
-          if (hit & (1u << s3)) push(kid(s3));
-          if (hit & (1u << s2)) push(kid(s2));
-          if (hit & (1u << s1)) push(kid(s1));
-          if (hit & (1u << s0)) push(kid(s0));
-        } else {
-          const dbl2 *lq = reinterpret_cast<const dbl2 *>(sc.leaves + ~cur);
-          const dbl2 l0 = lq[0], l1 = lq[1], l2 = lq[2];
-          const int4v lp = reinterpret_cast<const int4v *>(lq)[3];
-          const double lb[6] = {l0.x, l0.y, l1.x, l1.y, l2.x, l2.y};
-          auto lprim = [&](int i) { return i == 0 ? lp.x : i == 1 ? lp.y : i == 2 ? lp.z : lp.w; };
-          n_node++;
-          if (box_hit_v(lb, lb + 3, ray, t_min, closest_t)) {
-            if (lp.w != LEAF_INDIRECT && (room >= 4 || (room == 2 ? lp.z : lp.w) < 0)) {  // room >= 2 here
-              // up to four primitives named in the record, and room for them
+  for (int k = 0; k <= MIRT_CONE; k++) {
+    if (!((sc.kinds >> k) & 1)) continue;  // wave-uniform: the scene has no primitive of this kind
+    const int c = __popcll(__ballot(((w.km >> (8 * k)) & 0xffull) != 0));
+    if (c > most) {
+      most = c;
+      kind = k;
+    }
+  }
+  if (n_walk == 0 && most == 0) return false;  // a lane with a node always has room once nothing is pending
+  // walk, unless a full enough batch is waiting or too few lanes could take part
+  if (most < WIDE_DRAIN_MIN && (n_walk >= WIDE_WALK_MIN || most == 0)) {
+    if (walks) {
+      const int32_t cur = w.cur;
+      if (cur >= 0) {
+        // the whole 128-byte record in eight loads issued together
+        const flt4v *wq = reinterpret_cast<const flt4v *>(sc.wide + cur);
+        const flt4v f0 = wq[0], f1 = wq[1], f2 = wq[2], f3 = wq[3], f4 = wq[4], f5 = wq[5];
+        const int4v child = reinterpret_cast<const int4v *>(wq)[6];
+        const uint32_t o = reinterpret_cast<const uint32_t *>(wq)[28];
+        const float flo[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+        const float fhi[12] = {f3.x, f3.y, f3.z, f3.w, f4.x, f4.y, f4.z, f4.w, f5.x, f5.y, f5.z, f5.w};
+        auto kid = [&](int i) { return i == 0 ? child.x : i == 1 ? child.y : i == 2 ? child.z : child.w; };
+        n_node += 4;
+        uint32_t hit = 0;
 #pragma unroll
-              for (int k = 0; k < 4; k++) {
-                const int tag = lprim(k);
-                if (tag >= 0) {
-                  const int slot = __ffs(~used) - 1;
-                  pend[slot][tid] = tag & LEAF_PRIM_MASK;
-                  used |= 1u << slot;
-                  km |= (1ull << slot) << (8 * (tag >> LEAF_KIND_SHIFT));
-                }
+        for (int c = 0; c < 4; c++) {
+          const double lo[3] = {(double)flo[3 * c], (double)flo[3 * c + 1], (double)flo[3 * c + 2]};
+          const double hi[3] = {(double)fhi[3 * c], (double)fhi[3 * c + 1], (double)fhi[3 * c + 2]};
+          if (box_hit_v(lo, hi, ray, t_min, closest_t)) hit |= 1u << c;
+        }
+        // Visiting order of the binary ordered walk: the top node's two children, nearer first,
+        // and within each its own two children, nearer first.  order: 3 bits per binary node
+        // (top, first child, second child): axis, and bit 2 = the second child is the lower one.
+        const uint32_t up = w.up;
+        const bool t2 = (((o >> 2) & 1u) != 0) == (((up >> (o & 3u)) & 1u) != 0);
+        const bool a2 = (((o >> 5) & 1u) != 0) == (((up >> ((o >> 3) & 3u)) & 1u) != 0);
+        const bool b2 = (((o >> 8) & 1u) != 0) == (((up >> ((o >> 6) & 3u)) & 1u) != 0);
+        const int an = a2 ? 1 : 0, bn = b2 ? 3 : 2;  // the nearer slot of each pair
+        const int s0 = t2 ? bn : an, s1 = s0 ^ 1, s2 = t2 ? an : bn, s3 = s2 ^ 1;
+        // farthest first onto the stack, so that the nearest comes off first
+        if (hit & (1u << s3)) push(kid(s3));
+        if (hit & (1u << s2)) push(kid(s2));
+        if (hit & (1u << s1)) push(kid(s1));
+        if (hit & (1u << s0)) push(kid(s0));
+      } else {
+        const dbl2 *lq = reinterpret_cast<const dbl2 *>(sc.leaves + ~cur);
+        const dbl2 l0 = lq[0], l1 = lq[1], l2 = lq[2];
+        const int4v lp = reinterpret_cast<const int4v *>(lq)[3];
+        const double lb[6] = {l0.x, l0.y, l1.x, l1.y, l2.x, l2.y};
+        auto lprim = [&](int i) { return i == 0 ? lp.x : i == 1 ? lp.y : i == 2 ? lp.z : lp.w; };
+        n_node++;
+        if (box_hit_v(lb, lb + 3, ray, t_min, closest_t)) {
+          if (lp.w != LEAF_INDIRECT && (room >= 4 || (room == 2 ? lp.z : lp.w) < 0)) {  // room >= 2 here
+            // up to four primitives named in the record, and room for them
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const int tag = lprim(k);
+              if (tag >= 0) {
+                const int slot = __ffs(~w.used) - 1;
+                pend[slot][tid] = tag & LEAF_PRIM_MASK;
+                w.used |= 1u << slot;
+                w.km |= (1ull << slot) << (8 * (tag >> LEAF_KIND_SHIFT));
               }
-            } else {
-              // no room for them all, or a leaf of more than four (trees cut off at the depth limit): test here
-              const bool indirect = lp.w == LEAF_INDIRECT;
-              const int n = indirect ? lp.y : 4;
-              for (int k = 0; k < n; k++) {
-                const int tag = indirect ? rdonly(sc.leaf_tagged)[lp.x + k] : lprim(k);
-                if (tag >= 0) {
-                  const int pi = tag & LEAF_PRIM_MASK;
-                  n_prim++;
-                  isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
-                }
+            }
+          } else {
+            // no room for them all, or a leaf of more than four (trees cut off at the depth limit): test here
+            const bool indirect = lp.w == LEAF_INDIRECT;
+            const int n = indirect ? lp.y : 4;
+            for (int k = 0; k < n; k++) {
+              const int tag = indirect ? rdonly(sc.leaf_tagged)[lp.x + k] : lprim(k);
+              if (tag >= 0) {
+                const int pi = tag & LEAF_PRIM_MASK;
+                n_prim++;
+                isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
               }
             }
           }
         }
-        cur = sp > 0 ? pop() : WIDE_NONE;
       }
-      continue;
+      w.cur = w.sp > 0 ? pop() : WIDE_NONE;
     }
-    // too few lanes can walk: test a batch of the kind most lanes hold
-    int kind = 0, most = -1;
-#pragma unroll
-    for (int k = 0; k <= MIRT_CONE; k++) {
-      const int c = __popcll(__ballot(((km >> (8 * k)) & 0xffull) != 0));
-      if (c > most) {
-        most = c;
-        kind = k;
-      }
-    }
-    const uint32_t mine = (uint32_t)(km >> (8 * kind)) & 0xffu;
-    if (mine) {
-      const int slot = __ffs(mine) - 1;
-      const int pi = pend[slot][tid];
-      used &= ~(1u << slot);
-      km &= ~((1ull << slot) << (8 * kind));
-      n_prim++;
-      isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
-    }
+    return true;
+  }
+  // test a batch: every lane that holds a primitive of the kind most lanes hold tests one
+  const uint32_t mine = (uint32_t)(w.km >> (8 * kind)) & 0xffu;
+  if (mine) {
+    const int slot = __ffs(mine) - 1;
+    const int pi = pend[slot][tid];
+    w.used &= ~(1u << slot);
+    w.km &= ~((1ull << slot) << (8 * kind));
+    n_prim++;
+    isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+  }
+  return true;
+}
+
+template <bool SHADOW, bool UV, bool MOTION>
+DEV void traverse_wide(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
+                       Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
+  WideWalk w;
+  int32_t deep[WIDE_STACK_DEEP];  // private memory; touched only by lanes whose stack outgrows LDS
+  w.start(ray, active);
+  while (wide_step<SHADOW, UV, MOTION>(sc, ray, t_min, closest_t, best, w, deep, n_node, n_prim)) {
   }
 }
 
@@ -679,72 +714,56 @@ DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int 
 
 // One block of 256 rays: virtual block `vb` of the launch.  `active` and `j` locate the lane's queue
 // entry (unused by PRIMARY, whose virtual blocks are (16x16 pixel block, sample index) pairs).
-template <bool PRIMARY, bool UV, bool MOTION, int WALK>
-DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, unsigned &n_node, unsigned &n_prim) {
-  const DScene &sc = a.sc;
-  const mirt_config &cfg = a.fr.cfg;
-  const uint32_t shard = vb % QUEUE_SHARDS;  // of the two queues this block appends to
-#if MIRT_PROFILE == 1
-  PROF_DECL;
-#endif
-  d3 ro, rd, W;
+// One ray of a trace launch: where it comes from.
+struct RaySeed {
+  d3 ro, rd, W;  // origin, direction, the RGB weight with which its radiance enters the pixel
   double time;
   uint64_t key;
   uint32_t pixel;
-  if (PRIMARY) {
-    const uint32_t bs = vb;
-    const uint32_t block = a.first + bs / (uint32_t)a.fr.spp;
-    const uint32_t s = bs % (uint32_t)a.fr.spp;
-    int gx, gy;
-    active = block_pixel(a.fr, block, threadIdx.x, gx, gy, pixel);
-    key = mirt_rng_sample_key(cfg.seed, (uint32_t)(gy * a.fr.width + gx), s);
-    double u, v;
-    if (cfg.sampling == MIRT_SAMPLING_CENTRE) {  // deterministic parity mode
-      u = gx + 0.5;
-      v = gy + 0.5;
-      time = 0.5;
-    } else {  // Raytracer.cpp:533-538
-      u = gx + mirt_rng_draw(key, MIRT_DIM_JITTER_U);
-      v = gy + mirt_rng_draw(key, MIRT_DIM_JITTER_V);
-      time = cfg.enable_motion_blur ? mirt_rng_draw(key, MIRT_DIM_TIME) : 0.5;
-    }
-    camera_ray(a.fr.cam, u, v, a.fr.width, a.fr.height, key, ro, rd);
-    W = mk(1, 1, 1);
-  } else {
-    ro = mk(a.in.ox[j], a.in.oy[j], a.in.oz[j]);
-    rd = mk(a.in.dx[j], a.in.dy[j], a.in.dz[j]);
-    time = a.in.time[j];
-    W = mk(a.in.wr[j], a.in.wg[j], a.in.wb[j]);
-    key = a.in.key[j];
-    pixel = a.in.pixel[j];
+};
+// PRIMARY: the camera ray of virtual block `vb` = (16x16 pixel block, sample index), lane `p` of the
+// block (Raytracer.cpp:533-541); returns false for lanes outside the image.
+DEV bool primary_ray(const TraceArgs &a, uint32_t vb, uint32_t p, RaySeed &r) {
+  const mirt_config &cfg = a.fr.cfg;
+  const uint32_t block = a.first + vb / (uint32_t)a.fr.spp;
+  const uint32_t s = vb % (uint32_t)a.fr.spp;
+  int gx, gy;
+  const bool active = block_pixel(a.fr, block, p, gx, gy, r.pixel);
+  r.key = mirt_rng_sample_key(cfg.seed, (uint32_t)(gy * a.fr.width + gx), s);
+  double u, v;
+  if (cfg.sampling == MIRT_SAMPLING_CENTRE) {  // deterministic parity mode
+    u = gx + 0.5;
+    v = gy + 0.5;
+    r.time = 0.5;
+  } else {  // Raytracer.cpp:533-538
+    u = gx + mirt_rng_draw(r.key, MIRT_DIM_JITTER_U);
+    v = gy + mirt_rng_draw(r.key, MIRT_DIM_JITTER_V);
+    r.time = cfg.enable_motion_blur ? mirt_rng_draw(r.key, MIRT_DIM_TIME) : 0.5;
   }
+  camera_ray(a.fr.cam, u, v, a.fr.width, a.fr.height, r.key, r.ro, r.rd);
+  r.W = mk(1, 1, 1);
+  return active;
+}
+// entry j of the launch's input queue
+DEV void queued_ray(const TraceArgs &a, size_t j, RaySeed &r) {
+  r.ro = mk(a.in.ox[j], a.in.oy[j], a.in.oz[j]);
+  r.rd = mk(a.in.dx[j], a.in.dy[j], a.in.dz[j]);
+  r.time = a.in.time[j];
+  r.W = mk(a.in.wr[j], a.in.wg[j], a.in.wb[j]);
+  r.key = a.in.key[j];
+  r.pixel = a.in.pixel[j];
+}
 
-  const RayL ray = make_ray(ro, rd, time);
-  Best<UV> best;
-  BEST_IN_LDS(UV, best);
-  double closest = 1.7976931348623157e308;  // numeric_limits<double>::max() (Raytracer.cpp:300)
-#if MIRT_PROFILE == 1
-  PROF_MARK(0);
-#endif
-  // the ray's weight, key and pixel wait in LDS while the traversal needs the registers
-  __shared__ double park_w[3][256];
-  __shared__ uint64_t park_key[256];
-  __shared__ uint32_t park_pixel[256];
-  park_w[0][threadIdx.x] = W.x;
-  park_w[1][threadIdx.x] = W.y;
-  park_w[2][threadIdx.x] = W.z;
-  park_key[threadIdx.x] = key;
-  park_pixel[threadIdx.x] = pixel;
-  PARK_FENCE();
-  traverse<WALK, false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
-  PARK_FENCE();
-  W = mk(park_w[0][threadIdx.x], park_w[1][threadIdx.x], park_w[2][threadIdx.x]);
-  key = park_key[threadIdx.x];
-  pixel = park_pixel[threadIdx.x];
-#if MIRT_PROFILE == 1
-  PROF_MARK(1);
-#endif
-
+// What trace() does with the closest hit (Raytracer.cpp:305-472), for the lanes of the wave with
+// `active` set: background for a miss, local terms without visibility, one shadow work item per
+// contributing light, and the rays the hit spawns.  Must be called by all lanes of the wave; the
+// appends go to shard `shard` of the launch's queues.
+template <bool UV>
+DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const Best<UV> &best, bool active, d3 W,
+                    uint64_t key, uint32_t pixel) {
+  const DScene &sc = a.sc;
+  const mirt_config &cfg = a.fr.cfg;
+  const double time = ray.time;
   const bool hit = active && best.prim >= 0;
   if (active && !hit) pixel_add(a.accum, pixel, W * ld3(sc.background));  // Raytracer.cpp:472
 
@@ -799,9 +818,6 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
     }
   }
 
-#if MIRT_PROFILE == 1
-  PROF_MARK(2);
-#endif
   // per-light unshadowed Blinn-Phong terms -> shadow work items (Raytracer.cpp:262-286).  A light
   // that faces away from the shading normal adds exactly zero in the reference, so it gets no item.
   // First pass counts the wave's items so that ONE atomic reserves room for all of them; it decides
@@ -842,10 +858,6 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
     }
   }
 
-#if MIRT_PROFILE == 1
-  PROF_MARK(3);
-  if (!spawn) PROF_FLUSH(my_counters(a.counters));
-#endif
   if (!spawn) return;  // wave-uniform
 
   // ---- children: reflection (Raytracer.cpp:317-411; dropped when the glass branch returns `combined`),
@@ -906,8 +918,48 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
                   perp + sf.n * (-sqrt(maxd(0.0, disc))), time, wbase * (1.0 - fres),
                   mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFRACT), pixel);
   }
+}
+
+// One block of 256 rays: virtual block `vb` of the launch.  `active` and `j` locate the lane's queue
+// entry (unused by PRIMARY, whose virtual blocks are (16x16 pixel block, sample index) pairs).
+template <bool PRIMARY, bool UV, bool MOTION, int WALK>
+DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, unsigned &n_node, unsigned &n_prim) {
+  const DScene &sc = a.sc;
+  const uint32_t shard = vb % QUEUE_SHARDS;  // of the two queues this block appends to
 #if MIRT_PROFILE == 1
-  PROF_MARK(4);
+  PROF_DECL;
+#endif
+  RaySeed r;
+  if (PRIMARY) active = primary_ray(a, vb, threadIdx.x, r);
+  else queued_ray(a, j, r);
+  const RayL ray = make_ray(r.ro, r.rd, r.time);
+  Best<UV> best;
+  BEST_IN_LDS(UV, best);
+  double closest = 1.7976931348623157e308;  // numeric_limits<double>::max() (Raytracer.cpp:300)
+#if MIRT_PROFILE == 1
+  PROF_MARK(0);
+#endif
+  // the ray's weight, key and pixel wait in LDS while the traversal needs the registers
+  __shared__ double park_w[3][256];
+  __shared__ uint64_t park_key[256];
+  __shared__ uint32_t park_pixel[256];
+  park_w[0][threadIdx.x] = r.W.x;
+  park_w[1][threadIdx.x] = r.W.y;
+  park_w[2][threadIdx.x] = r.W.z;
+  park_key[threadIdx.x] = r.key;
+  park_pixel[threadIdx.x] = r.pixel;
+  PARK_FENCE();
+  traverse<WALK, false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
+  PARK_FENCE();
+  const d3 W = mk(park_w[0][threadIdx.x], park_w[1][threadIdx.x], park_w[2][threadIdx.x]);
+  const uint64_t key = park_key[threadIdx.x];
+  const uint32_t pixel = park_pixel[threadIdx.x];
+#if MIRT_PROFILE == 1
+  PROF_MARK(1);
+#endif
+  shade_hits<UV>(a, shard, ray, best, active, W, key, pixel);
+#if MIRT_PROFILE == 1
+  PROF_MARK(2);
   PROF_FLUSH(my_counters(a.counters));
 #endif
 }
@@ -931,6 +983,207 @@ __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_TRACE_WAVES) void k_
   count_add(&my_counters(a.counters)->node_tests, n_node);
   count_add(&my_counters(a.counters)->prim_tests, n_prim);
 #endif
+}
+
+
+// A resident wave's view of a sharded queue as one run of entries 0 .. total-1 (shard after shard),
+// and its hand-out of entry numbers: chunks of WORK_CHUNK taken off a launch-wide counter with one
+// atomic each, dealt to the lanes that ask.
+#ifndef REFILL_MIN
+#define REFILL_MIN 8  // hand out new work once this many lanes of a wave are idle
+#endif
+#define WORK_CHUNK 256u
+struct QueueRun {
+  uint32_t begin, slen;  // lane s < QUEUE_SHARDS: number of shard s's first entry, entries in shard s
+  uint32_t total;
+  DEV void open(const uint32_t *count, uint32_t shard_cap) {
+    const int lane = __lane_id();
+    slen = 0;
+    if (lane < QUEUE_SHARDS) {
+      const uint32_t c = count[lane * QUEUE_COUNT_STRIDE];
+      slen = c < shard_cap ? c : shard_cap;
+    }
+    uint32_t incl = slen;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    begin = incl - slen;
+    total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+  }
+  // slot of entry g in a queue whose shards hold shard_cap entries each
+  DEV size_t slot(uint32_t g, uint32_t shard_cap) const {
+    uint32_t shard = 0, at = 0;
+#pragma unroll 4
+    for (int sh = 0; sh < QUEUE_SHARDS; sh++) {
+      const uint32_t b0 = __builtin_amdgcn_readlane(begin, sh), l0 = __builtin_amdgcn_readlane(slen, sh);
+      if (g >= b0 && g - b0 < l0) {
+        shard = (uint32_t)sh;
+        at = g - b0;
+      }
+    }
+    return (size_t)shard * shard_cap + at;
+  }
+};
+struct WorkDealer {
+  uint32_t next = 0, end = 0;  // the wave's chunk (wave-uniform)
+  bool exhausted = false;      // the counter has passed `total` (wave-uniform)
+  // Deals entry numbers to the lanes with `want` set; returns true (and the number in g) for the
+  // lanes that got one.  Must be called by all lanes of the wave.
+  DEV bool deal(uint32_t *grab, uint32_t total, bool want, uint32_t &g) {
+    const int lane = __lane_id();
+    if (next == end) {
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(grab, WORK_CHUNK);
+      b = __builtin_amdgcn_readfirstlane(b);
+      next = b < total ? b : total;
+      end = b + WORK_CHUNK < total ? b + WORK_CHUNK : total;
+      exhausted = next == end;
+    }
+    const unsigned long long wm = __ballot(want);
+    g = next + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+    const bool take = want && g < end;
+    const uint32_t n_want = (uint32_t)__popcll(wm);
+    next = next + n_want < end ? next + n_want : end;
+    return take;
+  }
+};
+
+// k_trace for the wide walk, split in two so that lanes can take a new ray as soon as theirs has
+// found its closest hit (on a large scene a wave is otherwise as slow as its slowest ray, and the
+// shading code, if it has to run whenever a few lanes are ready, runs mostly empty):
+//   k_closest_stream   resident grid; a lane takes a ray number off the launch's work counter,
+//                      generates the camera ray or reads the queued one, walks, writes the hit
+//                      (primitive, distance, point, normal[, uv, tangent]) to hits[ray number];
+//   k_shade            one lane per ray number, full waves: rebuilds the ray, reads its hit, and does
+//                      what trace() does with it (shade_hits) -- no traversal code in this kernel.
+// Same rays, same hits, same shading and appends as k_trace.
+template <bool UV> DEV void hit_store(DHit *hits, DHitUV *hits_uv, size_t g, const Best<UV> &best) {
+  DHit h;
+  h.prim = best.prim;
+  h.pad = 0;
+  h.t = best.t;
+  d3 p = mk(0, 0, 0), n = mk(0, 0, 0);
+  if (best.prim >= 0) {
+    p = best.p();
+    n = best.n();
+  }
+  h.p[0] = p.x; h.p[1] = p.y; h.p[2] = p.z;
+  h.n[0] = n.x; h.n[1] = n.y; h.n[2] = n.z;
+  hits[g] = h;
+  if constexpr (UV) {
+    if (best.prim >= 0) {
+      DHitUV x;
+      const d3 t = best.tan();
+      x.u = best.u();
+      x.v = best.v();
+      x.tan[0] = t.x; x.tan[1] = t.y; x.tan[2] = t.z;
+      x.pad = 0;
+      hits_uv[g] = x;
+    }
+  }
+}
+template <bool UV> DEV void hit_load(const DHit *hits, const DHitUV *hits_uv, size_t g, Best<UV> &best) {
+  const DHit h = hits[g];
+  best.prim = h.prim;
+  best.t = h.t;
+  best.set_p(ld3(h.p));
+  best.set_n(ld3(h.n));
+  if constexpr (UV) {
+    if (h.prim >= 0) {
+      const DHitUV x = hits_uv[g];
+      best.set_uv(x.u, x.v);
+      best.set_tan(ld3(x.tan));
+    }
+  }
+}
+
+template <bool PRIMARY, bool UV, bool MOTION>
+__global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_closest_stream(const TraceArgs a) {
+  const DScene &sc = a.sc;
+  unsigned n_node = 0, n_prim = 0;
+  QueueRun run;
+  if (PRIMARY) {
+    run.begin = run.slen = 0;
+    run.total = a.n * (uint32_t)a.fr.spp * 256u;  // (pixel block, sample, lane of the block)
+  } else {
+    run.open(a.in_count, a.in.shard_cap);
+  }
+  WorkDealer dealer;
+  bool has_ray = false;
+  uint32_t mine = 0;  // the number of the ray in hand
+  RayL ray = make_ray(mk(0, 0, 0), mk(0, 0, 1), 0.5);
+  double closest = 0.0;
+  Best<UV> best;
+  BEST_IN_LDS(UV, best);
+  WideWalk w;
+  int32_t deep[WIDE_STACK_DEEP];
+  w.start(ray, false);
+  for (;;) {
+    if (has_ray && !w.busy()) {  // found (or nothing to find): the hit goes out, the lane is free
+      hit_store<UV>(a.hits, a.hits_uv, mine, best);
+      has_ray = false;
+    }
+    const bool want = !has_ray;
+    if (!dealer.exhausted && ((int)__popcll(__ballot(want)) >= REFILL_MIN || !__any(has_ray))) {
+      uint32_t g;
+      const bool take = dealer.deal(a.grab, run.total, want, g);
+      RaySeed r;
+      bool ok = take;
+      if (PRIMARY) {
+        const bool inside = primary_ray(a, g >> 8, g & 255u, r);
+        ok = take && inside;  // numbers that fall outside the image get no hit record; k_shade skips them too
+      } else {
+        queued_ray(a, run.slot(g, a.in.shard_cap), r);  // (lanes that took nothing read entry 0 and drop it)
+      }
+      if (ok) {
+        ray = make_ray(r.ro, r.rd, r.time);
+        closest = 1.7976931348623157e308;  // numeric_limits<double>::max() (Raytracer.cpp:300)
+        best.prim = -1;
+        best.t = 0;
+        mine = g;
+        has_ray = true;
+        w.start(ray, true);
+      }
+    }
+    if (!__any(has_ray)) {
+      if (dealer.exhausted) break;
+      continue;
+    }
+    wide_step<false, UV, MOTION>(sc, ray, 1e-5, closest, best, w, deep, n_node, n_prim);
+  }
+  count_add(&my_counters(a.counters)->node_tests, n_node);
+  count_add(&my_counters(a.counters)->prim_tests, n_prim);
+}
+
+// Ray number g = virtual block vb * 256 + lane, the numbering k_closest_stream used.
+template <bool PRIMARY, bool UV>
+__global__ __launch_bounds__(256) void k_shade(const TraceArgs a) {
+  QueueRun run;
+  if (PRIMARY) {
+    run.begin = run.slen = 0;
+    run.total = a.n * (uint32_t)a.fr.spp * 256u;
+  } else {
+    run.open(a.in_count, a.in.shard_cap);
+  }
+  const uint32_t n_vb = (run.total + 255u) >> 8;
+  for (uint32_t vb = blockIdx.x; vb < n_vb; vb += gridDim.x) {
+    const uint32_t g = vb * 256u + threadIdx.x;
+    bool active = g < run.total;
+    RaySeed r;
+    if (PRIMARY) {
+      const bool inside = primary_ray(a, vb, threadIdx.x, r);
+      active = active && inside;
+    } else {
+      queued_ray(a, run.slot(active ? g : 0, a.in.shard_cap), r);
+    }
+    const RayL ray = make_ray(r.ro, r.rd, r.time);
+    Best<UV> best;
+    BEST_IN_LDS(UV, best);
+    if (active) hit_load<UV>(a.hits, a.hits_uv, g, best);
+    shade_hits<UV>(a, vb % QUEUE_SHARDS, ray, best, active, r.W, r.key, r.pixel);
+  }
 }
 
 
@@ -1082,6 +1335,154 @@ __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k
   count_add(&my_counters(a.counters)->shadow_prim_tests, n_prim);
   count_add(&my_counters(a.counters)->shadow_segments, n_seg);
 #endif
+}
+
+
+// k_shadow for the wide walk, with lanes that take their next work item as soon as they have
+// finished one.  In k_shadow a wave is done with its 64 items when the slowest is, and on a large
+// scene the slowest is slow: shadow rays from deep inside a cloud of primitives visit hundreds of
+// boxes, rays that start near its edge a handful (measured: 7 of 64 lanes busy per vector instruction).
+// Here the grid is resident (a few blocks per CU); a wave takes items off the launch's queue in chunks
+// (one atomic per WORK_CHUNK items) and hands them to its idle lanes whenever at least REFILL_MIN
+// lanes are idle, between steps of the walk.  What a lane does with an item is shadow_block's state
+// machine unchanged: strata, segments through transparent objects, attenuation, one pixel add.
+__global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_shadow_stream(const ShadowArgs a) {
+  __shared__ double park_p[3][256], park_c[3][256], park_w[4][256], park_inv_n[256];  // park_w: total att cur dist
+  __shared__ uint64_t park_key[256];
+  __shared__ uint32_t park_pixel[256], park_light[256], park_dim[256];
+  __shared__ int32_t park_side[256], park_s[256];
+  const DScene &sc = a.sc;
+  const mirt_config &cfg = a.fr.cfg;
+  const int tid = threadIdx.x, lane = __lane_id();
+  unsigned n_node = 0, n_prim = 0, n_seg = 0;
+
+  QueueRun run;
+  run.open(a.count, a.shard_cap);
+  WorkDealer dealer;
+  bool has_item = false;
+  RayL ray = make_ray(mk(0, 0, 0), mk(0, 0, 1), 0.5);
+  double eps = 0.0, closest = 0.0;
+  Best<false> best;
+  best.rec = nullptr;
+  best.prim = -1;
+  best.t = 0;
+  WideWalk w;
+  int32_t deep[WIDE_STACK_DEEP];
+  w.start(ray, false);
+
+  // Moves the lane to the next stratum that has a segment to walk and starts that segment; false
+  // when all strata are done.  Strata state lives in LDS (park_s, park_w).
+  auto begin_segment = [&](d3 P, d3 dir, double cur, double dist) {
+    ray = make_ray(P + dir * cur, dir, 0.5);
+    closest = dist - cur;
+    best.prim = -1;
+    best.t = 0;
+    n_seg++;
+    w.start(ray, true);
+  };
+  auto next_stratum = [&]() {
+    const int side = park_side[tid], n = side * side;
+    int s = park_s[tid];
+    if (s >= n) return false;
+    const uint32_t li = park_light[tid];
+    const mirt_light &L = sc.lights[li];
+    const uint64_t key = park_key[tid];
+    const uint32_t dim0 = park_dim[tid];
+    const d3 P = mk(park_p[0][tid], park_p[1][tid], park_p[2][tid]);
+    while (s < n) {
+      const int si = s / side, sj = s % side;
+      const uint32_t dim = dim0 + 2u * (uint32_t)s;
+      const double u = (si + mirt_rng_draw(key, dim)) / side;
+      const double v = (sj + mirt_rng_draw(key, dim + 1)) / side;
+      const d3 to = light_point(L, a.fr.light_frame[li], u, v) - P;
+      const double dist = len(to);
+      const d3 dir = to / dist;
+      if (eps < dist) {
+        park_s[tid] = s;
+        park_w[1][tid] = 1.0;  // att
+        park_w[2][tid] = eps;  // cur
+        park_w[3][tid] = dist;
+        begin_segment(P, dir, eps, dist);
+        return true;
+      }
+      s++;  // nothing to walk: this stratum is unoccluded
+    }
+    park_s[tid] = s;
+    return false;
+  };
+  auto finish_item = [&]() {
+    const double shadow = park_w[0][tid] * park_inv_n[tid];
+    if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
+      pixel_add(a.accum, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
+    has_item = false;
+  };
+
+  for (;;) {
+    // ---- hand idle lanes their next item -----------------------------------------------------
+    const bool want = !has_item;
+    if (!dealer.exhausted && ((int)__popcll(__ballot(want)) >= REFILL_MIN || !__any(has_item))) {
+      uint32_t g;
+      const bool take = dealer.deal(a.grab, run.total, want, g);
+      const size_t at = run.slot(g, a.shard_cap);
+      if (take) {
+        const DShadowItem it = a.items[at];
+        const DLightFrame lf = a.fr.light_frame[it.light];
+        park_p[0][tid] = it.p[0];
+        park_p[1][tid] = it.p[1];
+        park_p[2][tid] = it.p[2];
+        park_c[0][tid] = it.c[0];
+        park_c[1][tid] = it.c[1];
+        park_c[2][tid] = it.c[2];
+        park_key[tid] = it.key;
+        park_pixel[tid] = it.pixel;
+        park_light[tid] = it.light;
+        park_dim[tid] = lf.dim;
+        park_side[tid] = lf.side;
+        park_inv_n[tid] = lf.inv_n;
+        park_s[tid] = 0;
+        park_w[0][tid] = 0.0;  // total
+        eps = cfg.ray_offset_epsilon;
+        if (cfg.use_adaptive_epsilon) eps += len(ld3(it.p)) * cfg.adaptive_epsilon_scale;
+        has_item = true;
+        if (!next_stratum()) finish_item();
+      }
+    }
+    if (!__any(has_item)) {
+      if (dealer.exhausted) break;
+      continue;  // nothing in hand but the queue is not empty: refill (the condition above holds now)
+    }
+    // ---- one step of the walk ----------------------------------------------------------------------
+    wide_step<true, false, false>(sc, ray, eps, closest, best, w, deep, n_node, n_prim);
+    // ---- lanes whose segment is over ---------------------------------------------------------------
+    if (has_item && !w.busy()) {
+      double att = park_w[1][tid], cur = park_w[2][tid];
+      const double dist = park_w[3][tid];
+      bool done = true;
+      if (best.prim >= 0 && best.t < (dist - cur)) {
+        const double tr = sc.prim_transparency[best.prim];
+        if (tr > 0.0) {
+          const double opacity = 1.0 - tr;
+          att *= (1.0 - opacity);
+          cur += best.t + eps;
+          done = (att < 0.01) || !(cur < dist);
+        } else {
+          att = 0.0;
+        }
+      }
+      if (!done) {  // on through the transparent object: the next segment of the same stratum
+        park_w[1][tid] = att;
+        park_w[2][tid] = cur;
+        begin_segment(mk(park_p[0][tid], park_p[1][tid], park_p[2][tid]), ray.d, cur, dist);
+      } else {
+        park_w[0][tid] += (1.0 - att);
+        park_s[tid] += 1;
+        if (!next_stratum()) finish_item();
+      }
+    }
+  }
+  count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
+  count_add(&my_counters(a.counters)->shadow_prim_tests, n_prim);
+  count_add(&my_counters(a.counters)->shadow_segments, n_seg);
 }
 
 
