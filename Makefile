@@ -46,10 +46,12 @@ $(BUILD)/kernels.o: $(CSRC)/kernels.hip $(ENGINE_HDRS) Makefile | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 $(BUILD)/engine.o: $(CSRC)/engine.cpp $(ENGINE_HDRS) $(HOST)/mirt_math.h Makefile | $(BUILD)
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
+$(BUILD)/multi.o: $(CSRC)/multi.cpp $(ENGINE_HDRS) Makefile | $(BUILD)
+	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
 $(BUILD)/engine_math.o: $(HOST)/mirt_math.cpp $(HOST)/mirt_math.h | $(BUILD)
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
-$(LIB)/libmirt.so: $(BUILD)/kernels.o $(BUILD)/engine.o $(BUILD)/engine_math.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+$(LIB)/libmirt.so: $(BUILD)/kernels.o $(BUILD)/engine.o $(BUILD)/multi.o $(BUILD)/engine_math.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 $(LIB)/libmirt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIB)/libmirt.so | $(LIB)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -L$(LIB) -lmirt -Wl,-rpath,'$$ORIGIN'

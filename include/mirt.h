@@ -290,6 +290,25 @@ enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE =
        MIRT_TRAVERSAL_WIDE = 4 };
 int mirt_scene_set_traversal(mirt_scene *scene, int mode);
 
+/* Several GPUs in one process.  No counterpart in the reference, whose only parallelism is the OpenMP
+ * row loop (Raytracer.cpp:525): a group replicates the scene on every device named (one mirt_scene
+ * each), mirt_group_render deals the image's 16x16 tiles round-robin (tile t to member t % n), lets
+ * all members render their share at the same time, gathers the shares on the first device with RCCL
+ * (ncclSend / ncclRecv over xGMI; hipMemcpyPeerAsync where RCCL is missing or a device is named twice
+ * -- mirt_group_transport() names what is in use) and writes the frame to rgb_out (host, as
+ * mirt_render).  stats: sums over the members, device_ms their maximum; member_stats: NULL or
+ * mirt_group_size() entries, one per member. */
+#define MIRT_GROUP_MAX 16
+#define MIRT_GROUP_TILE 16
+typedef struct mirt_group mirt_group;
+int mirt_group_create(const mirt_scene_desc *desc, const int *devices, int n_devices, mirt_group **out);
+void mirt_group_destroy(mirt_group *group);
+int mirt_group_size(const mirt_group *group);
+const char *mirt_group_transport(const mirt_group *group);
+int mirt_group_set_traversal(mirt_group *group, int mode);
+int mirt_group_render(mirt_group *group, const mirt_camera *camera, const mirt_config *config, int width,
+                      int height, int spp, double *rgb_out, mirt_stats *stats, mirt_stats *member_stats);
+
 const char *mirt_last_error(void);
 int mirt_abi_version(void);
 

@@ -91,6 +91,8 @@ ENGINE_SYMBOLS = [
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
     "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal", "mirt_render_tiles_begin", "mirt_render_tiles_end",
     "mirt_last_error", "mirt_abi_version", "mirt_render_tiles_noalloc", "mirt_noalloc_scratch_bytes",
+    "mirt_group_create", "mirt_group_destroy", "mirt_group_size", "mirt_group_transport", "mirt_group_set_traversal",
+    "mirt_group_render",
 ]
 
 
@@ -111,6 +113,15 @@ def _declare_engine(lib):
     lib.mirt_render_tiles_end.argtypes = [C.c_void_p, C.c_int, C.POINTER(Stats)]
     lib.mirt_render_tiles_noalloc.argtypes = lib.mirt_render_tiles.argtypes
     lib.mirt_noalloc_scratch_bytes.restype = C.c_uint64
+    lib.mirt_group_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    lib.mirt_group_destroy.argtypes = [C.c_void_p]
+    lib.mirt_group_destroy.restype = None
+    lib.mirt_group_size.argtypes = [C.c_void_p]
+    lib.mirt_group_transport.argtypes = [C.c_void_p]
+    lib.mirt_group_transport.restype = C.c_char_p
+    lib.mirt_group_set_traversal.argtypes = [C.c_void_p, C.c_int]
+    lib.mirt_group_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Config), C.c_int, C.c_int, C.c_int, dp,
+                                      C.POINTER(Stats), C.POINTER(Stats)]
     lib.mirt_tile_buffer_pixels.argtypes = [C.c_int] * 6
     lib.mirt_tile_buffer_pixels.restype = C.c_int64
     lib.mirt_trace_ids.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, dp]

@@ -194,6 +194,49 @@ class DeviceScene:
         return out
 
 
+class DeviceGroup:
+    """A scene replicated on several GPUs of this process (mirt_group_create); frames are split into
+    16x16 tiles dealt round-robin and gathered on the first device."""
+
+    def __init__(self, scene, devices):
+        self._lib = A.engine_lib()
+        self._h = C.c_void_p()
+        desc = scene.desc if isinstance(scene, HostScene) else scene
+        self._keep = scene
+        devs = (C.c_int * len(devices))(*devices)
+        _check(self._lib.mirt_group_create(C.byref(desc), devs, len(devices), C.byref(self._h)), "mirt_group_create")
+        self.devices = list(devices)
+
+    @property
+    def transport(self):
+        return self._lib.mirt_group_transport(self._h).decode()
+
+    def set_traversal(self, mode):
+        code = {"auto": 0, "packet": 1, "lane": 2, "ordered": 3, "wide": 4}[mode]
+        _check(self._lib.mirt_group_set_traversal(self._h, code), "mirt_group_set_traversal")
+
+    def close(self):
+        if self._h:
+            self._lib.mirt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera, config, width, height, spp):
+        """One frame: (height, width, 3) float64 array, summed stats, per-member stats."""
+        out = np.empty((height, width, 3), dtype=np.float64)
+        st = A.Stats()
+        per = (A.Stats * len(self.devices))()
+        _check(self._lib.mirt_group_render(self._h, C.byref(camera), C.byref(config), width, height, spp,
+                                           out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st), per),
+               "mirt_group_render")
+        return out, st.as_dict(), [p.as_dict() for p in per]
+
+
 def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 

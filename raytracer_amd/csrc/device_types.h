@@ -261,6 +261,15 @@ struct RaysArgs {
   double *t, *normal;
 };
 
+// Tiles of a group's members, gathered side by side on the root device, into the frame (multi.cpp).
+struct DeinterleaveArgs {
+  const double *gathered;
+  double *frame;
+  int32_t width, height, tile, tiles_x, world, pad;
+  uint64_t offset[MIRT_GROUP_MAX];  // in doubles: where member r's tiles start in `gathered`
+};
+void launch_deinterleave(unsigned grid, void *stream, const DeinterleaveArgs &a);
+
 // Launchers defined in kernels.hip (the only translation unit compiled for the GPU).
 // walk: WALK_* (wave-coherent, per lane in the reference's order, per lane nearer child first, 4-wide and batched);
 // uv: the scene samples image maps, so hits carry texture coordinates and a tangent frame;

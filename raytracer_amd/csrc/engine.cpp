@@ -114,6 +114,16 @@ struct SpawnKinds {
 
 }  // namespace
 
+// for the other translation units of the library: records the message of mirt_last_error()
+int mirt_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  return fail(code, "%s", buf);
+}
+
 struct mirt_scene {
   int device = 0;
   int walk = WALK_PACKET;  // BVH walk (WALK_*)

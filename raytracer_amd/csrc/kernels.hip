@@ -98,6 +98,10 @@ void launch_shadow_stream(unsigned grid, void *stream, const ShadowArgs &a) {
   hipLaunchKernelGGL(k_shadow_stream, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
 }
 
+void launch_deinterleave(unsigned grid, void *stream, const DeinterleaveArgs &a) {
+  hipLaunchKernelGGL(k_deinterleave, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+}
+
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a) {
   hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
 }

@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
   __shared__ int32_t park_side[256], park_s[256];
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
-  const int tid = threadIdx.x, lane = __lane_id();
+  const int tid = threadIdx.x;
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
 
   QueueRun run;
@@ -1510,6 +1510,21 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
   a.out[3 * (size_t)i + 2] = c[2];
 }
 
+
+// Pixel (x, y) of the frame from the compact tile buffer of the member that rendered it: tile t of the
+// row-major tile grid belongs to member t % world and is that member's tile number t / world.
+__global__ __launch_bounds__(256) void k_deinterleave(const DeinterleaveArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= (size_t)a.width * a.height) return;
+  const int x = (int)(i % a.width), y = (int)(i / a.width);
+  const int t = (y / a.tile) * a.tiles_x + x / a.tile;
+  const int r = t % a.world, slot = t / a.world;
+  const double *src = a.gathered + a.offset[r] +
+                      3 * ((size_t)slot * a.tile * a.tile + (size_t)(y % a.tile) * a.tile + (x % a.tile));
+  a.frame[3 * i] = src[0];
+  a.frame[3 * i + 1] = src[1];
+  a.frame[3 * i + 2] = src[2];
+}
 
 // Closest hit of the pixel-centre camera rays at time 0.5 (pinhole): the parity hook.
 template <int WALK>

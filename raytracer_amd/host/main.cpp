@@ -1,5 +1,6 @@
 // Command line of the drop-in renderer: the flags, defaults and exit codes of the reference's
 // `raytracer` binary (Code/Core/Main.cpp:19-207), plus --seed, --device and --binary-ppm for the engine.
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -32,6 +33,7 @@ void print_help(const char *prog) {
             << "  --log-level <level>      Set log level (debug, info, warn, error)\n"
             << "  --seed <n>               Seed of the sampling sequence (default: 0)\n"
             << "  --device <n>             HIP device to render on (default: 0)\n"
+            << "  --devices <n>            Split every frame over n GPUs, device .. device + n - 1 (default: 1)\n"
             << "  --binary-ppm             Write the image as binary PPM (P6) instead of ASCII (P3)\n"
             << "  --help                   Display this help message\n";
 }
@@ -75,6 +77,7 @@ void parse_arguments(int argc, char *argv[]) {
     else if (a == "--log-level" && left >= 1) g_config.log_level = argv[++i];
     else if (a == "--seed" && left >= 1) g_config.seed = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "--device" && left >= 1) g_config.device = std::atoi(argv[++i]);
+    else if (a == "--devices" && left >= 1) g_config.devices = std::max(1, std::atoi(argv[++i]));
     else if (a == "--binary-ppm") g_config.output_format = "p6";
     else {
       host_log(LogLevel::Error, "Unknown argument arg=%s", a.c_str());

@@ -193,9 +193,10 @@ struct RenderConfig {
   double glass_absorption_strength = 0.1;
   double pure_emission_threshold = 4.0;
   // engine additions (no counterpart in the reference): seed of the addressed random function,
-  // HIP device to render on
+  // HIP device to render on, number of GPUs to split a frame over (devices device .. device + devices - 1)
   unsigned long long seed = 0;
   int device = 0;
+  int devices = 1;
 };
 extern RenderConfig g_config;
 
@@ -230,7 +231,8 @@ class Raytracer {
  private:
   const Scene &scene;
   std::unique_ptr<FlatScene> flat;
-  mirt_scene *device_scene = nullptr;
+  mirt_scene *device_scene = nullptr;  // one GPU ...
+  struct mirt_group *device_group = nullptr;  // ... or several (g_config.devices > 1)
   std::unique_ptr<mirt_stats> stats;
 };
 

@@ -28,11 +28,25 @@ Raytracer::Raytracer(const Scene &s) : scene(s), stats(new mirt_stats) {
            flat->max_depth);
   host_log(LogLevel::Info, "Preloaded textures count=%d", static_cast<int>(flat->textures.size()));
   const mirt_scene_desc d = flat->desc();
-  if (mirt_scene_create(&d, g_config.device, &device_scene) != MIRT_OK)
+  if (g_config.devices > 1) {
+    // the frame's tiles are dealt to `devices` GPUs, each with its own replica of the scene
+    std::vector<int> devs;
+    // (MIRT_DEVICES_SAME=1 puts every member on `device`: a rehearsal of the several-GPU path on one GPU)
+    const bool same = std::getenv("MIRT_DEVICES_SAME") != nullptr;
+    for (int i = 0; i < g_config.devices; ++i) devs.push_back(g_config.device + (same ? 0 : i));
+    if (mirt_group_create(&d, devs.data(), g_config.devices, &device_group) != MIRT_OK)
+      throw std::runtime_error(std::string("mirt_group_create: ") + mirt_last_error());
+    host_log(LogLevel::Info, "Rendering on %d GPUs, frame gathered by %s", g_config.devices,
+             mirt_group_transport(device_group));
+  } else if (mirt_scene_create(&d, g_config.device, &device_scene) != MIRT_OK) {
     throw std::runtime_error(std::string("mirt_scene_create: ") + mirt_last_error());
+  }
 }
 
-Raytracer::~Raytracer() { mirt_scene_destroy(device_scene); }
+Raytracer::~Raytracer() {
+  mirt_scene_destroy(device_scene);
+  mirt_group_destroy(device_group);
+}
 
 const mirt_stats &Raytracer::last_stats() const { return *stats; }
 
@@ -43,8 +57,11 @@ Image Raytracer::render(const Camera &camera, int width, int height, int samples
   const mirt_config cfg = flatten_config(g_config);
   std::vector<double> rgb(static_cast<std::size_t>(width) * height * 3);
   const auto t0 = std::chrono::steady_clock::now();
-  if (mirt_render(device_scene, &cam, &cfg, width, height, samples_per_pixel, rgb.data(), stats.get()) != MIRT_OK)
-    throw std::runtime_error(std::string("mirt_render: ") + mirt_last_error());
+  const int rc = device_group
+                     ? mirt_group_render(device_group, &cam, &cfg, width, height, samples_per_pixel, rgb.data(),
+                                         stats.get(), nullptr)
+                     : mirt_render(device_scene, &cam, &cfg, width, height, samples_per_pixel, rgb.data(), stats.get());
+  if (rc != MIRT_OK) throw std::runtime_error(std::string("mirt_render: ") + mirt_last_error());
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (int y = 0; y < height; ++y)
     for (int x = 0; x < width; ++x) {

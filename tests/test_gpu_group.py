@@ -1,0 +1,74 @@
+"""Several GPUs behind the C ABI (mirt_group_*): the frame a group renders is the frame one GPU renders.
+On a box with one GPU the group's members all sit on device 0: that exercises everything but RCCL's
+transfers between devices (RCCL wants one rank per device; the group then moves the buffers with
+hipMemcpyPeerAsync and says so), and a one-member group goes through RCCL's calls with itself as peer."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, ROOT
+from raytracer_amd import DeviceGroup, default_config, read_ppm
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
+            "shadow_prim_tests")
+
+
+@pytest.mark.parametrize("members", [1, 3, 8])
+def test_group_frame_equals_single_gpu_frame(members, host_scenes, device_scenes):
+    hs, ds = host_scenes("Test5"), device_scenes("Test5")
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=5, glossy_samples=2)
+    w, h, spp = 200, 117, 2  # not a multiple of the tile size in either direction
+    want, st = ds.render(cam, cfg, w, h, spp)
+    grp = DeviceGroup(hs, [0] * members)
+    print(f"{members} member(s): {grp.transport}")
+    assert grp.transport.startswith("RCCL") == (members == 1)
+    for _ in range(2):  # buffers and communicators are reused frame after frame
+        got, total, per = grp.render(cam, cfg, w, h, spp)
+        assert np.abs(got - want).max() <= 1e-12
+        for k in COUNTERS:
+            assert total[k] == st[k], k
+        assert sum(p["primary_rays"] for p in per) == w * h * spp and len(per) == members
+    if members > 1:
+        assert min(p["primary_rays"] for p in per) > 0  # everybody got tiles
+    grp.close()
+
+
+def test_group_on_a_large_scene_and_bad_arguments(host_scenes):
+    from raytracer_amd import HostScene, DeviceScene, MirtError
+    hs = HostScene.synthetic(20000)
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=3)
+    want, _ = DeviceScene(hs, 0).render(cam, cfg, 96, 54, 1)
+    grp = DeviceGroup(hs, [0, 0])
+    got, _, _ = grp.render(cam, cfg, 96, 54, 1)
+    assert np.abs(got - want).max() <= 1e-12
+    with pytest.raises(MirtError):
+        grp.render(cam, cfg, 0, 54, 1)
+    with pytest.raises(MirtError):
+        DeviceGroup(hs, [])
+    with pytest.raises(MirtError):
+        DeviceGroup(hs, [99])
+
+
+def test_cli_devices_flag(tmp_path):
+    """`raytracer --devices 2` (both on GPU 0 here: MIRT_DEVICES_SAME=1) writes the image `--devices 1` writes."""
+    import os
+    cli = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    args = ["--scene", "ASCII/Test4.txt", "--resolution", "160", "90", "--samples", "2", "--max-depth", "4"]
+    one, two = str(tmp_path / "one.ppm"), str(tmp_path / "two.ppm")
+    r = subprocess.run([cli, *args, "--output", one], cwd=FIXTURES, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, MIRT_DEVICES_SAME="1")
+    r = subprocess.run([cli, *args, "--devices", "2", "--output", two], cwd=FIXTURES, capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "2 GPUs" in r.stdout + r.stderr
+    a, _ = read_ppm(one)
+    b, _ = read_ppm(two)
+    assert (np.abs(a - b) > 1e-9).mean() < 1e-4  # a value on a rounding boundary may flip with the order of the sums
