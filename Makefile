@@ -25,7 +25,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -Iinclude -I$(CSRC) -Wal
 # with the reference's
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra -Iinclude -I$(HOST)
 
-.PHONY: all engine host cli oracle clean
+.PHONY: all engine host cli oracle clean test-all benchmark $(addprefix test-,1 2 3 4 5 6 7)
 all: engine host cli oracle
 
 engine: $(LIB)/libmirt.so
@@ -61,6 +61,30 @@ $(BIN)/raytracer: $(HOST)/main.cpp $(LIB)/libmirt_host.so | $(BIN)
 
 oracle:
 	$(MAKE) -C oracle all
+
+# ---- render recipes: the settings of the reference's `make test-1 ... test-7`, `test-all` and `benchmark`
+# (reference Makefile:161-163,185,222-301), through the drop-in command line on the GPU.  Run from fixtures/
+# (the renderer looks for Textures/ in its working directory); images go to $(OUT_DIR).
+OUT_DIR ?= $(CURDIR)/Output
+RAYTRACER := $(CURDIR)/$(BIN)/raytracer
+TEST_1 := --resolution 1920 1080 --light-intensity 0.02 --ambient-light 0.8 --samples 16 --soft-shadows 4 --glossy-reflection 4 --max-depth 5
+TEST_2 := --resolution 1920 1080 --light-intensity 0.008 --ambient-light 1 --samples 4 --soft-shadows 4 --glossy-reflection 4 --max-depth 2
+TEST_3 := --resolution 720 400 --light-intensity 0.02 --ambient-light 0.8 --samples 4 --soft-shadows 2 --max-depth 2
+TEST_4 := --resolution 720 400 --light-intensity 0.02 --ambient-light 1 --samples 4 --soft-shadows 16 --glossy-reflection 16 --max-depth 16
+TEST_5 := --resolution 720 400 --light-intensity 0.02 --ambient-light 1 --samples 4 --soft-shadows 8 --glossy-reflection 8 --motion-blur 12 --max-depth 64
+TEST_6 := --resolution 720 400 --light-intensity 0.05 --ambient-light 1 --samples 16 --soft-shadows 4 --glossy-reflection 4 --max-depth 5
+TEST_7 := --resolution 800 400 --samples 4 --light-intensity 0.1 --ambient-light 1 --soft-shadows 4 --glossy-reflection 4 --max-depth 12
+$(OUT_DIR):
+	mkdir -p $@
+define RECIPE
+test-$(1): cli | $$(OUT_DIR)
+	cd fixtures && $$(RAYTRACER) --scene ASCII/Test$(1).txt --output $$(OUT_DIR)/rendered_bvh_Test$(1).ppm $$(TEST_$(1)) $$(RENDER_FLAGS)
+endef
+$(foreach n,1 2 3 4 5 6 7,$(eval $(call RECIPE,$(n))))
+test-all: test-1 test-2 test-3 test-4 test-5 test-6 test-7
+SCENE_FILE ?= Test5.txt
+benchmark: cli | $(OUT_DIR)
+	cd fixtures && time $(RAYTRACER) --scene ASCII/$(SCENE_FILE) --output $(OUT_DIR)/benchmark.ppm $(RENDER_FLAGS)
 
 clean:
 	rm -rf $(LIB) $(BIN)

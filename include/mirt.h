@@ -278,6 +278,18 @@ int mirt_render_tiles_noalloc(mirt_scene *scene, const mirt_camera *camera, cons
                               double *d_rgb_out, void *stream, mirt_stats *stats);
 uint64_t mirt_noalloc_scratch_bytes(void);
 
+/* Progress feed.  The reference times every image row and appends "row,milliseconds" to
+ * Output/render_row_times.csv as the rows finish (Raytracer.cpp:518-521,527,573-584).  The engine
+ * renders all rows at once; with recording on, every block of primary samples notes the device's wall
+ * clock when its samples have been shaded, per band of 16 pixel rows (cost: two atomics per 256
+ * samples).  mirt_scene_progress returns the number of bands of the last frame and fills
+ * band_ms[0 .. min(bands, max_bands)) with the time, in milliseconds since the frame's first block
+ * started, at which the last primary sample of band b (pixel rows 16b .. 16b+15) was shaded -- shadow
+ * and secondary rays of the band may still be in flight then.  Bands this rank owns no tile of read 0.
+ * mirt_render_tiles_noalloc leaves the feed out. */
+int mirt_scene_record_progress(mirt_scene *scene, int enable);
+int mirt_scene_progress(mirt_scene *scene, double *band_ms, int max_bands);
+
 /* Engine tuning, no counterpart in the reference: how rays walk the BVH.
  * PACKET (one node index per wave) and LANE (one per ray) test the same boxes and primitives in the
  * same order per ray as intersect_bvh (Bvh.cpp:306-333) and return the same hits, exact ties included.

@@ -145,6 +145,18 @@ class DeviceScene:
                                      out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)), "mirt_render")
         return out, st.as_dict()
 
+    def record_progress(self, enable=True):
+        _check(self._lib.mirt_scene_record_progress(self._h, 1 if enable else 0), "mirt_scene_record_progress")
+
+    def progress(self):
+        """Milliseconds (since the last frame's first block started) at which each band of 16 pixel
+        rows had its primary samples shaded; empty when recording is off."""
+        n = self._lib.mirt_scene_progress(self._h, None, 0)
+        out = np.zeros(max(n, 0), dtype=np.float64)
+        if n > 0:
+            self._lib.mirt_scene_progress(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return out
+
     def render_tiles(self, camera, config, width, height, spp, tile_w, tile_h, rank, world, out_ptr, stream=None):
         """This rank's tiles into the device buffer at `out_ptr` (see mirt_render_tiles)."""
         st = A.Stats()

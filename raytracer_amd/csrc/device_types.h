@@ -219,6 +219,7 @@ struct TraceArgs {
   DCounters *counters;       // COUNTER_SHARDS replicas
   uint32_t first;            // PRIMARY: first 16x16 block of this launch
   uint32_t n;                // PRIMARY: number of blocks
+  unsigned long long *progress;  // PRIMARY, optional: [0] earliest start, [1 + r] latest finish of 16-pixel row band r (wall clock)
   uint32_t *grab;            // k_closest_stream: the next ray number nobody has taken yet (zero at launch)
   DHit *hits;                // k_closest_stream -> k_shade, one per ray number
   DHitUV *hits_uv;

@@ -171,6 +171,12 @@ struct mirt_scene {
   char *scratch = nullptr;  // device address of this GPU's static array (scratch_address)
   std::vector<DLightFrame> light_frame_host;
   DeviceBuffer out, ids;
+  // progress feed (mirt_scene_record_progress): wall clock per band of 16 pixel rows, and the last frame's read-back
+  bool record_progress = false;
+  DeviceBuffer progress;
+  std::vector<unsigned long long> progress_host;
+  int progress_bands = 0;
+  double wall_clock_khz = 100000.0;
   uint64_t split_for = 0;  // frame shape (primary grid blocks, depth, glossy samples) `split` was found for
   uint32_t split = 1;      // primary launches are cut this many times finer than the queues' sizes suggest
   int light_frame_for = 0;  // shadow_samples the device copy of the lights' strata was made for
@@ -651,6 +657,9 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     sc->resident_grid = (unsigned)env_size("MIRT_RESIDENT_BLOCKS", (size_t)std::max(cus, 1) * 3);
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
+      sc->wall_clock_khz = khz;
     const char *st = std::getenv("MIRT_STREAM");
     sc->stream_kernels = !(st && st[0] == '0');
   }
@@ -1011,6 +1020,15 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
     HIP_TRY(hipMemsetAsync(ws->accum.p, 0, n_pixels * 3 * sizeof(double), stream));
   ws->accum_clean = false;
 
+  unsigned long long *progress = nullptr;
+  if (sc->record_progress && !ws->fixed) {  // (the set that never allocates leaves the feed out)
+    sc->progress_bands = (ws->height + 15) / 16;
+    const size_t bytes = (size_t)(sc->progress_bands + 1) * sizeof(unsigned long long);
+    HIP_TRY(sc->progress.reserve(bytes));
+    HIP_TRY(hipMemsetAsync(sc->progress.p, 0, bytes, stream));
+    HIP_TRY(hipMemsetAsync(sc->progress.p, 0xff, sizeof(unsigned long long), stream));  // earliest start: none yet
+    progress = sc->progress.as<unsigned long long>();
+  }
   for (size_t c = 0; c < chunks && levels > 0; ++c) {
     const uint64_t b0 = c * per_launch;
     const uint32_t nb = (uint32_t)std::min<uint64_t>(per_launch, total_blocks - b0);
@@ -1036,6 +1054,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       a.first = (uint32_t)b0;
       a.n = nb;
       a.depth = depth;
+      a.progress = depth == 0 ? progress : nullptr;
       Timed t{nullptr, nullptr, 0};
       if (kernel_timing) {
         HIP_TRY(get_event(ws, ev_used, t.a));
@@ -1147,6 +1166,11 @@ int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
     if (int rc = enqueue_frame(sc, ws)) return rc;
   }
 
+  if (sc->record_progress && !ws->fixed && sc->progress.p) {
+    sc->progress_host.resize((size_t)sc->progress_bands + 1);
+    HIP_TRY(hipMemcpy(sc->progress_host.data(), sc->progress.p, sc->progress_host.size() * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
+  }
   if (stats) {
     const DCounters *host_counters = reinterpret_cast<const DCounters *>(ws->pinned);
     const FrameShape shape = frame_shape(ws->camera, ws->config, ws->width, ws->height, ws->spp, ws->tile_w, ws->tile_h,
@@ -1210,6 +1234,7 @@ int begin_frame(mirt_scene *sc, int slot, const mirt_camera *camera, const mirt_
   mirt_scene::WorkSet *ws = slot == 2 ? &sc->fixed_work : &sc->work[slot];  // 2: the set that never allocates
   if (ws->pending) return fail(MIRT_ERR_INVALID, "slot %d still holds a frame: call mirt_render_tiles_end first", slot);
   HIP_TRY(hipSetDevice(sc->device));
+  (void)hipGetLastError();  // an error some earlier, failed call left behind is not this frame's
   ws->camera = *camera;
   ws->config = *config;
   ws->width = width;
@@ -1274,6 +1299,28 @@ MIRT_API int mirt_render_tiles_noalloc(mirt_scene *scene, const mirt_camera *cam
 }
 
 MIRT_API uint64_t mirt_noalloc_scratch_bytes(void) { return MIRT_SCRATCH_BYTES; }
+
+MIRT_API int mirt_scene_record_progress(mirt_scene *scene, int enable) {
+  if (!scene) return fail(MIRT_ERR_INVALID, "NULL scene");
+  scene->record_progress = enable != 0;
+  if (!enable) scene->progress_host.clear();
+  return MIRT_OK;
+}
+
+MIRT_API int mirt_scene_progress(mirt_scene *scene, double *band_ms, int max_bands) {
+  if (!scene || (!band_ms && max_bands > 0)) return fail(MIRT_ERR_INVALID, "NULL argument");
+  const std::vector<unsigned long long> &p = scene->progress_host;
+  if (p.size() < 2) return 0;
+  const int n = std::min<int>(max_bands, (int)p.size() - 1);
+  unsigned long long start = p[0];
+  if (start == ~0ull) {  // no start was noted: count from the earliest finish
+    for (size_t i = 1; i < p.size(); ++i)
+      if (p[i]) start = std::min(start, p[i]);
+  }
+  for (int i = 0; i < n; ++i)
+    band_ms[i] = p[i + 1] >= start && p[i + 1] ? (double)(p[i + 1] - start) / scene->wall_clock_khz : 0.0;
+  return (int)p.size() - 1;
+}
 
 MIRT_API int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
                          int height, int spp, double *rgb_out, mirt_stats *stats) {

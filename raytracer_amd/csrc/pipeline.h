@@ -714,6 +714,20 @@ DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int 
 
 // One block of 256 rays: virtual block `vb` of the launch.  `active` and `j` locate the lane's queue
 // entry (unused by PRIMARY, whose virtual blocks are (16x16 pixel block, sample index) pairs).
+// Progress feed (the reference times every image row, Raytracer.cpp:527,573-584): when asked for, a
+// primary block notes the wall clock when it starts and when its samples are shaded, per band of 16
+// pixel rows.  One lane per block, two atomics; nothing when a.progress is NULL.
+DEV void progress_mark(const TraceArgs &a, uint32_t vb, bool finished) {
+  if (!a.progress || threadIdx.x != 0) return;
+  const uint32_t block = a.first + vb / (uint32_t)a.fr.spp;
+  int gx, gy;
+  uint32_t px;
+  block_pixel(a.fr, block, 0, gx, gy, px);
+  const unsigned long long now = wall_clock64();
+  if (finished) atomicMax(a.progress + 1 + gy / 16, now);
+  else atomicMin(a.progress, now);
+}
+
 // One ray of a trace launch: where it comes from.
 struct RaySeed {
   d3 ro, rd, W;  // origin, direction, the RGB weight with which its radiance enters the pixel
@@ -930,8 +944,12 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
   PROF_DECL;
 #endif
   RaySeed r;
-  if (PRIMARY) active = primary_ray(a, vb, threadIdx.x, r);
-  else queued_ray(a, j, r);
+  if (PRIMARY) {
+    progress_mark(a, vb, false);
+    active = primary_ray(a, vb, threadIdx.x, r);
+  } else {
+    queued_ray(a, j, r);
+  }
   const RayL ray = make_ray(r.ro, r.rd, r.time);
   Best<UV> best;
   BEST_IN_LDS(UV, best);
@@ -958,6 +976,7 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
   PROF_MARK(1);
 #endif
   shade_hits<UV>(a, shard, ray, best, active, W, key, pixel);
+  if (PRIMARY) progress_mark(a, vb, true);
 #if MIRT_PROFILE == 1
   PROF_MARK(2);
   PROF_FLUSH(my_counters(a.counters));
@@ -1110,6 +1129,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_cl
   } else {
     run.open(a.in_count, a.in.shard_cap);
   }
+  if (PRIMARY && a.progress && threadIdx.x == 0) atomicMin(a.progress, (unsigned long long)wall_clock64());
   WorkDealer dealer;
   bool has_ray = false;
   uint32_t mine = 0;  // the number of the ray in hand
@@ -1183,6 +1203,7 @@ __global__ __launch_bounds__(256) void k_shade(const TraceArgs a) {
     BEST_IN_LDS(UV, best);
     if (active) hit_load<UV>(a.hits, a.hits_uv, g, best);
     shade_hits<UV>(a, vb % QUEUE_SHARDS, ray, best, active, r.W, r.key, r.pixel);
+    if (PRIMARY) progress_mark(a, vb, true);
   }
 }
 

@@ -56,13 +56,25 @@ Image Raytracer::render(const Camera &camera, int width, int height, int samples
   const mirt_camera cam = flatten_camera(camera);
   const mirt_config cfg = flatten_config(g_config);
   std::vector<double> rgb(static_cast<std::size_t>(width) * height * 3);
+  // Like the reference, row times go to Output/render_row_times.csv when that directory exists in the
+  // working directory (Raytracer.cpp:518-521); here: when the last primary sample of the row's band
+  // of 16 rows was shaded, in milliseconds since the frame started (single-GPU renders only).
+  std::FILE *csv = device_scene ? std::fopen("Output/render_row_times.csv", "w") : nullptr;
+  if (device_scene) mirt_scene_record_progress(device_scene, csv != nullptr);
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = device_group
                      ? mirt_group_render(device_group, &cam, &cfg, width, height, samples_per_pixel, rgb.data(),
                                          stats.get(), nullptr)
                      : mirt_render(device_scene, &cam, &cfg, width, height, samples_per_pixel, rgb.data(), stats.get());
-  if (rc != MIRT_OK) throw std::runtime_error(std::string("mirt_render: ") + mirt_last_error());
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (csv) {
+    std::vector<double> band((static_cast<std::size_t>(height) + 15) / 16, 0.0);
+    if (rc == MIRT_OK) mirt_scene_progress(device_scene, band.data(), static_cast<int>(band.size()));
+    std::fprintf(csv, "Row,Time(ms)\n");
+    for (int y = 0; y < height; ++y) std::fprintf(csv, "%d,%.3f\n", y, band[static_cast<std::size_t>(y) / 16]);
+    std::fclose(csv);
+  }
+  if (rc != MIRT_OK) throw std::runtime_error(std::string("mirt_render: ") + mirt_last_error());
   for (int y = 0; y < height; ++y)
     for (int x = 0; x < width; ++x) {
       const double *p = &rgb[(static_cast<std::size_t>(y) * width + x) * 3];
