@@ -140,6 +140,7 @@ struct DFrame {
   int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world;
   int32_t blocks_x, blocks_y;  // 16x16-pixel thread blocks per tile
   int32_t n_slots;             // tiles owned by this rank
+  uint32_t plane;              // pixels of this rank's tile buffer: the accumulator is three planes of that many doubles
   const struct DLightFrame *light_frame;  // per light, per frame (depends on cfg.shadow_samples)
 };
 
@@ -215,7 +216,7 @@ struct TraceArgs {
   uint32_t *shadow_count;
   uint32_t shadow_shard_cap;
   int32_t depth;             // depth of the rays this launch traces
-  double *accum;             // 3 doubles per pixel of this rank's tile buffer
+  double *accum;             // this rank's tile buffer: a red, a green and a blue plane of fr.plane doubles
   DCounters *counters;       // COUNTER_SHARDS replicas
   uint32_t first;            // PRIMARY: first 16x16 block of this launch
   uint32_t n;                // PRIMARY: number of blocks

@@ -853,6 +853,7 @@ FrameShape frame_shape(const mirt_camera &camera, const mirt_config &config, int
   f.tiles = (int64_t)fr.tiles_x * fr.tiles_y;
   fr.n_slots = (int32_t)(f.tiles > rank ? (f.tiles - rank + world - 1) / world : 0);
   f.n_pixels = (size_t)fr.n_slots * tile_w * tile_h;
+  fr.plane = (uint32_t)f.n_pixels;
   f.total_blocks = (uint64_t)fr.n_slots * fr.blocks_x * fr.blocks_y;
   return f;
 }

@@ -658,11 +658,14 @@ template <class L> DEV d3 light_point(const L &l, const DLightFrame &lf, double 
   return ld3(l.location) + right * (r * cs * (l.area_size[0] * 0.5)) + up * (r * sn * (l.area_size[1] * 0.5));
 }
 
-DEV void pixel_add(double *accum, uint32_t pixel, d3 c) {
-  double *p = accum + 3 * (size_t)pixel;
-  unsafeAtomicAdd(p, c.x);
-  unsafeAtomicAdd(p + 1, c.y);
-  unsafeAtomicAdd(p + 2, c.z);
+// The accumulator is kept as three planes, not as pixel triples: the 64 pixels a wave adds to are mostly
+// neighbours, and one atomic instruction over neighbours in a plane touches a third of the cache lines
+// it would touch across triples (the atomic units work a line at a time).  Adding zero is skipped.
+DEV void pixel_add(double *accum, uint32_t plane, uint32_t pixel, d3 c) {
+  double *p = accum + pixel;
+  if (c.x != 0.0) unsafeAtomicAdd(p, c.x);
+  if (c.y != 0.0) unsafeAtomicAdd(p + plane, c.y);
+  if (c.z != 0.0) unsafeAtomicAdd(p + 2 * (size_t)plane, c.z);
 }
 
 // Appending to the block's shard of a ray queue: the wave counts what it is going to append, one lane
@@ -828,7 +831,7 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
   const mirt_config &cfg = a.fr.cfg;
   const double time = ray.time;
   const bool hit = active && best.prim >= 0;
-  if (active && !hit) pixel_add(a.accum, pixel, W * ld3(sc.background));  // Raytracer.cpp:472
+  if (active && !hit) pixel_add(a.accum, a.fr.plane, pixel, W * ld3(sc.background));  // Raytracer.cpp:472
 
   // ---- shading of the hit (Raytracer.cpp:305-466), visibility deferred to k_shadow ------------
   const bool spawn = a.depth + 1 < cfg.max_ray_depth;  // deeper rays would return black (Raytracer.cpp:297)
@@ -878,7 +881,7 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
       local = W * local;
       lit = !(T >= cfg.pure_glass_threshold);  // pure glass is not shaded (Raytracer.cpp:307-311)
       if (lit) local = local + wd * (amb * cfg.ambient_factor);
-      pixel_add(a.accum, pixel, local);
+      pixel_add(a.accum, a.fr.plane, pixel, local);
     }
   }
 
@@ -1384,7 +1387,7 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
   if (valid) {
     const double shadow = total * park_inv_n[tid];
     if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
-      pixel_add(a.accum, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
+      pixel_add(a.accum, a.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
   }
 #if MIRT_PROFILE == 2
   PROF_MARK(3);
@@ -1485,7 +1488,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
   auto finish_item = [&]() {
     const double shadow = park_w[0][tid] * park_inv_n[tid];
     if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
-      pixel_add(a.accum, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
+      pixel_add(a.accum, a.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
     has_item = false;
   };
 
@@ -1566,8 +1569,8 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
   double c[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    double x = a.accum[3 * (size_t)i + k] / a.spp;
-    a.accum[3 * (size_t)i + k] = 0.0;
+    double x = a.accum[(size_t)k * a.n_pixels + i] / a.spp;
+    a.accum[(size_t)k * a.n_pixels + i] = 0.0;
     if (a.cfg.tone_mapping_mode == MIRT_TONEMAP_REINHARD) {
       x = x / (1.0 + x);
     } else if (a.cfg.tone_mapping_mode == MIRT_TONEMAP_EXPOSURE) {
