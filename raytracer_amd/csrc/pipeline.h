@@ -658,6 +658,51 @@ template <class L> DEV d3 light_point(const L &l, const DLightFrame &lf, double 
   return ld3(l.location) + right * (r * cs * (l.area_size[0] * 0.5)) + up * (r * sn * (l.area_size[1] * 0.5));
 }
 
+// What a shadow item needs of its light before it can start, for the first LIGHT_TABLE_MAX lights of
+// the scene, in LDS: read from memory, these are two more dependent round trips after the item's own
+// (the item names the light, the light's records hold the rest), and the set-up of an item is a third
+// of the shadow kernel's time.  Lights beyond the table are read from memory as before.
+#define LIGHT_TABLE_MAX 32
+struct LightTable {
+  double loc[LIGHT_TABLE_MAX][3];
+  double inv_n[LIGHT_TABLE_MAX];
+  uint32_t dim[LIGHT_TABLE_MAX];
+  int32_t side[LIGHT_TABLE_MAX];
+  int32_t type[LIGHT_TABLE_MAX];
+};
+DEV void light_table_fill(LightTable &t, const DScene &sc, const DFrame &fr) {
+  for (int i = (int)threadIdx.x; i < sc.n_lights && i < LIGHT_TABLE_MAX; i += (int)blockDim.x) {
+    const DLightFrame lf = fr.light_frame[i];
+    t.loc[i][0] = sc.lights[i].location[0];
+    t.loc[i][1] = sc.lights[i].location[1];
+    t.loc[i][2] = sc.lights[i].location[2];
+    t.inv_n[i] = lf.inv_n;
+    t.dim[i] = lf.dim;
+    t.side[i] = lf.side;
+    t.type[i] = sc.lights[i].type;
+  }
+  __syncthreads();
+}
+DEV int light_side(const LightTable &t, const DFrame &fr, uint32_t li) {
+  return li < LIGHT_TABLE_MAX ? t.side[li] : fr.light_frame[li].side;
+}
+DEV double light_inv_n(const LightTable &t, const DFrame &fr, uint32_t li) {
+  return li < LIGHT_TABLE_MAX ? t.inv_n[li] : fr.light_frame[li].inv_n;
+}
+
+// The point of stratum s (of side x side) on light li, for the sample whose key is `key`
+// (Raytracer.cpp:160-170).  A light that is not an area light has one point and spends no draw on it.
+DEV d3 stratum_point(const LightTable &t, const DScene &sc, const DFrame &fr, uint32_t li, uint64_t key, int s, int side) {
+  const bool tabled = li < LIGHT_TABLE_MAX;
+  const int type = tabled ? t.type[li] : sc.lights[li].type;
+  if (type != MIRT_LIGHT_AREA) return tabled ? mk(t.loc[li][0], t.loc[li][1], t.loc[li][2]) : ld3(sc.lights[li].location);
+  const int si = s / side, sj = s % side;
+  const uint32_t dim = (tabled ? t.dim[li] : fr.light_frame[li].dim) + 2u * (uint32_t)s;
+  const double u = (si + mirt_rng_draw(key, dim)) / side;
+  const double v = (sj + mirt_rng_draw(key, dim + 1)) / side;
+  return light_point(sc.lights[li], fr.light_frame[li], u, v);
+}
+
 // The accumulator is kept as three planes, not as pixel triples: the 64 pixels a wave adds to are mostly
 // neighbours, and one atomic instruction over neighbours in a plane touches a third of the cache lines
 // it would touch across triples (the atomic units work a line at a time).  Adding zero is skipped.
@@ -1272,13 +1317,12 @@ __global__ __launch_bounds__(256) void k_shade(const TraceArgs a) {
 // key, light) stay in memory: the traversal with its inlined intersectors sets the kernel's vector
 // register peak, and every register freed there counts towards one more resident wave per SIMD.
 template <int WALK>
-DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_node, unsigned &n_prim,
-                      unsigned &n_seg) {
-  // per lane: the item (point, colour, key, pixel, light), the light's strata, and the walk state
-  __shared__ double park_p[3][256], park_c[3][256], park_w[4][256], park_inv_n[256];  // park_w: total att cur dist
+DEV void shadow_block(const ShadowArgs &a, const LightTable &lights, bool valid, size_t slot, unsigned &n_node,
+                      unsigned &n_prim, unsigned &n_seg) {
+  // per lane: the item (point, colour, key, pixel, light) and the walk state
+  __shared__ double park_p[3][256], park_c[3][256], park_w[4][256];  // park_w: total att cur dist
   __shared__ uint64_t park_key[256];
-  __shared__ uint32_t park_pixel[256], park_light[256], park_dim[256];
-  __shared__ int32_t park_side[256];
+  __shared__ uint32_t park_pixel[256], park_light[256];
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
   const int tid = threadIdx.x;
@@ -1288,7 +1332,6 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
   d3 P;
   {
     const DShadowItem it = a.items[slot];
-    const DLightFrame lf = a.fr.light_frame[it.light];
     P = ld3(it.p);
     park_p[0][tid] = it.p[0];
     park_p[1][tid] = it.p[1];
@@ -1299,9 +1342,6 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
     park_key[tid] = it.key;
     park_pixel[tid] = it.pixel;
     park_light[tid] = it.light;
-    park_dim[tid] = lf.dim;
-    park_side[tid] = lf.side;
-    park_inv_n[tid] = lf.inv_n;
   }
   double eps = cfg.ray_offset_epsilon;
   if (cfg.use_adaptive_epsilon) eps += len(P) * cfg.adaptive_epsilon_scale;
@@ -1312,17 +1352,12 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
   bool busy = false;
   // moves to the next stratum that has a segment to walk; returns false when all strata are done
   auto next_stratum = [&]() {
-    const int side = park_side[tid], n = side * side;
+    const uint32_t li = park_light[tid];
+    const int side = light_side(lights, a.fr, li), n = side * side;
     if (s >= n) return false;
-    const mirt_light &L = sc.lights[park_light[tid]];
     const uint64_t key = park_key[tid];
-    const uint32_t dim0 = park_dim[tid];
     while (s < n) {
-      const int si = s / side, sj = s % side;
-      const uint32_t dim = dim0 + 2u * (uint32_t)s;
-      const double u = (si + mirt_rng_draw(key, dim)) / side;
-      const double v = (sj + mirt_rng_draw(key, dim + 1)) / side;
-      const d3 to = light_point(L, a.fr.light_frame[park_light[tid]], u, v) - P;
+      const d3 to = stratum_point(lights, sc, a.fr, li, key, s, side) - P;
       dist = len(to);
       dir = to / dist;
       att = 1.0;
@@ -1385,7 +1420,7 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
     }
   }
   if (valid) {
-    const double shadow = total * park_inv_n[tid];
+    const double shadow = total * light_inv_n(lights, a.fr, park_light[tid]);
     if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
       pixel_add(a.accum, a.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
   }
@@ -1399,11 +1434,13 @@ DEV void shadow_block(const ShadowArgs &a, bool valid, size_t slot, unsigned &n_
 template <int WALK>
 __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
+  __shared__ LightTable lights;
+  light_table_fill(lights, a.sc, a.fr);
   const WaveView v = wave_view(a.count, a.shard_cap);
   for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
     size_t slot;
     const bool valid = view_entry(v, vb, a.shard_cap, slot);
-    shadow_block<WALK>(a, valid, slot, n_node, n_prim, n_seg);
+    shadow_block<WALK>(a, lights, valid, slot, n_node, n_prim, n_seg);
   }
 #ifndef MIRT_PROFILE
   count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
@@ -1422,14 +1459,16 @@ __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k
 // lanes are idle, between steps of the walk.  What a lane does with an item is shadow_block's state
 // machine unchanged: strata, segments through transparent objects, attenuation, one pixel add.
 __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_shadow_stream(const ShadowArgs a) {
-  __shared__ double park_p[3][256], park_c[3][256], park_w[4][256], park_inv_n[256];  // park_w: total att cur dist
+  __shared__ double park_p[3][256], park_c[3][256], park_w[4][256];  // park_w: total att cur dist
   __shared__ uint64_t park_key[256];
-  __shared__ uint32_t park_pixel[256], park_light[256], park_dim[256];
-  __shared__ int32_t park_side[256], park_s[256];
+  __shared__ uint32_t park_pixel[256], park_light[256];
+  __shared__ int32_t park_s[256];
+  __shared__ LightTable lights;
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
   const int tid = threadIdx.x;
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
+  light_table_fill(lights, sc, a.fr);
 
   QueueRun run;
   run.open(a.count, a.shard_cap);
@@ -1456,20 +1495,14 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
     w.start(ray, true);
   };
   auto next_stratum = [&]() {
-    const int side = park_side[tid], n = side * side;
+    const uint32_t li = park_light[tid];
+    const int side = light_side(lights, a.fr, li), n = side * side;
     int s = park_s[tid];
     if (s >= n) return false;
-    const uint32_t li = park_light[tid];
-    const mirt_light &L = sc.lights[li];
     const uint64_t key = park_key[tid];
-    const uint32_t dim0 = park_dim[tid];
     const d3 P = mk(park_p[0][tid], park_p[1][tid], park_p[2][tid]);
     while (s < n) {
-      const int si = s / side, sj = s % side;
-      const uint32_t dim = dim0 + 2u * (uint32_t)s;
-      const double u = (si + mirt_rng_draw(key, dim)) / side;
-      const double v = (sj + mirt_rng_draw(key, dim + 1)) / side;
-      const d3 to = light_point(L, a.fr.light_frame[li], u, v) - P;
+      const d3 to = stratum_point(lights, sc, a.fr, li, key, s, side) - P;
       const double dist = len(to);
       const d3 dir = to / dist;
       if (eps < dist) {
@@ -1486,7 +1519,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
     return false;
   };
   auto finish_item = [&]() {
-    const double shadow = park_w[0][tid] * park_inv_n[tid];
+    const double shadow = park_w[0][tid] * light_inv_n(lights, a.fr, park_light[tid]);
     if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
       pixel_add(a.accum, a.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
     has_item = false;
@@ -1501,7 +1534,6 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
       const size_t at = run.slot(g, a.shard_cap);
       if (take) {
         const DShadowItem it = a.items[at];
-        const DLightFrame lf = a.fr.light_frame[it.light];
         park_p[0][tid] = it.p[0];
         park_p[1][tid] = it.p[1];
         park_p[2][tid] = it.p[2];
@@ -1511,9 +1543,6 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
         park_key[tid] = it.key;
         park_pixel[tid] = it.pixel;
         park_light[tid] = it.light;
-        park_dim[tid] = lf.dim;
-        park_side[tid] = lf.side;
-        park_inv_n[tid] = lf.inv_n;
         park_s[tid] = 0;
         park_w[0][tid] = 0.0;  // total
         eps = cfg.ray_offset_epsilon;
