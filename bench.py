@@ -42,16 +42,22 @@ def bytes_per_ray(n_node, n_prim):
     return 2 * RAY_B + 2 * HIT_B + n_node * NODE_B + n_prim * PRIM_B
 
 
-def cpu_baseline(args, rays_per_sample):
+def cpu_baseline(args, rays_per_sample, shadow_per_sample):
     """Times the CPU path on the same workload (rank 0, N = 1 only): the unmodified reference program
     built by oracle/Makefile (kind "reference") renders the whole bench frame where that takes seconds
-    (Test5), a stated fraction of its pixels where it would take minutes (the 64-spp configuration); the
+    (Test5 at 16 spp), the frame at a stated fraction of its pixels where it would take minutes; the
     generated cloud, which the reference could only read as a gigabyte of text, and a box without the
     reference build time the CPU restatement in oracle/ instead (kind "port")."""
     cores = int(os.environ.get("OMP_NUM_THREADS") or min(os.cpu_count() or 1, 16))
     ref = os.path.join(ROOT, "oracle", "_ref", "raytracer_ref")
     scene_name, spp, depth = args.scene, args.spp, args.max_depth
-    shrink = 4 if spp > 16 else 1  # per axis
+    # bounded sample: the frame is shrunk per axis until its rays + shadow segments (as the engine counted
+    # them) come to about 20 s of the reference at the rate it shows on Test5 (35 M segments/s on 16 cores)
+    work = args.width * args.height * spp * (rays_per_sample + shadow_per_sample)
+    shrink = 1
+    while work / (shrink * shrink) > 7e8 * cores / 16 and shrink < 16:
+        shrink *= 2
+    print(f"bench.py: timing the CPU baseline (1/{shrink * shrink} of the frame's pixels) ...", file=sys.stderr, flush=True)
     width, height = args.width // shrink, args.height // shrink
     sample = (f"{scene_name} {width}x{height} {spp} spp max-depth {depth}: "
               + ("the whole bench frame" if shrink == 1 else f"the bench frame at 1/{shrink * shrink} of its pixels"))
@@ -365,7 +371,7 @@ def main():
                                  "memory traffic and is not a fraction of anything (the scene stays in cache)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, line["rays_per_sample"])
+            line["cpu_baseline"] = cpu_baseline(args, line["rays_per_sample"], line["shadow_segments_per_sample"])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

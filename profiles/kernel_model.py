@@ -24,7 +24,11 @@ OUT = os.path.join(HERE, "kernel_model.json")
 
 
 def klass(name):
-    return "k_trace" if "k_trace" in name else "k_shadow" if "k_shadow" in name else "k_resolve" if "k_resolve" in name else None
+    """The class a launch is timed under by the engine: closest hit + shading (one kernel, or the
+    k_closest_stream / k_shade pair on large scenes), shadow segments (k_shadow or k_shadow_stream)."""
+    if "k_trace" in name or "k_closest_stream" in name or "k_shade<" in name or "k_shade(" in name:
+        return "k_trace"
+    return "k_shadow" if "k_shadow" in name else "k_resolve" if "k_resolve" in name else None
 
 
 def one_pass(run, n):
