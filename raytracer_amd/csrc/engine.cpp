@@ -635,9 +635,28 @@ MIRT_API int mirt_scene_set_traversal(mirt_scene *scene, int mode) {
   return MIRT_OK;
 }
 
+namespace {
+int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out);
+}
+
+// No exception leaves the library: the host-side tables of a scene are std::vectors, and a scene of
+// 10^6 primitives on a small host can run out of memory while they are filled.
 MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
   if (!out) return fail(MIRT_ERR_INVALID, "out is NULL");
   *out = nullptr;
+  try {
+    return scene_create(desc, device, out);
+  } catch (const std::bad_alloc &) {
+    *out = nullptr;
+    return fail(MIRT_ERR_MEMORY, "out of host memory while preparing the scene");
+  } catch (const std::exception &e) {
+    *out = nullptr;
+    return fail(MIRT_ERR_INVALID, "scene preparation failed: %s", e.what());
+  }
+}
+
+namespace {
+int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
   if (int rc = validate(desc)) return rc;
   int n_dev = 0;
   HIP_TRY(hipGetDeviceCount(&n_dev));
@@ -796,6 +815,7 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   *out = sc;
   return MIRT_OK;
 }
+}  // namespace
 
 MIRT_API int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int tile_h, int rank, int world) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;

@@ -131,8 +131,12 @@ MIRT_API int mirt_group_create(const mirt_scene_desc *desc, const int *devices, 
   *out = nullptr;
   if (!devices || n_devices < 1 || n_devices > MIRT_GROUP_MAX)
     return mirt_fail(MIRT_ERR_INVALID, "a group has 1 to %d members", MIRT_GROUP_MAX);
-  mirt_group *g = new (std::nothrow) mirt_group;
-  if (!g) return mirt_fail(MIRT_ERR_MEMORY, "out of host memory");
+  mirt_group *g = nullptr;
+  try {
+    g = new mirt_group;
+  } catch (const std::exception &) {
+    return mirt_fail(MIRT_ERR_MEMORY, "out of host memory");
+  }
   struct Guard {
     mirt_group *g;
     ~Guard() { mirt_group_destroy(g); }
