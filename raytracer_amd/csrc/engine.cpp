@@ -181,6 +181,7 @@ struct mirt_scene {
   uint32_t split = 1;      // primary launches are cut this many times finer than the queues' sizes suggest
   int light_frame_for = 0;  // shadow_samples the device copy of the lights' strata was made for
   bool light_frame_valid = false;
+  bool any_strata = false;  // some light of the current light-frame table has more than one stratum
   ~mirt_scene() {
     if (null_stream_mark) (void)hipEventDestroy(null_stream_mark);
     if (stream) (void)hipStreamDestroy(stream);
@@ -895,12 +896,14 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   if (n_lights && (sc->light_frame_for != config->shadow_samples || !sc->light_frame_valid)) {
     std::vector<DLightFrame> &lf = sc->light_frame_host;  // n_lights entries since the scene was created
     uint32_t dim = MIRT_DIM_SHADOW;
+    sc->any_strata = false;
     for (int l = 0; l < n_lights; ++l) {
       const mirt_light &L = sc->host_lights[l];
       int samples = (L.type == MIRT_LIGHT_AREA) ? std::max(1, L.samples) : 1;
       if (config->shadow_samples > 0 && L.type == MIRT_LIGHT_AREA) samples = config->shadow_samples;
       int side = static_cast<int>(std::sqrt(samples));
       if (side * side == 0) side = 1;
+      if (side > 1) sc->any_strata = true;
       lf[l].dim = dim;
       lf[l].side = side;
       lf[l].inv_n = 1.0 / (side * side);
@@ -1124,7 +1127,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
         sa.grab = a.shadow_count + 1;  // a spare word of the launch's tail block, zeroed with it
         launch_shadow_stream(sc->resident_grid, stream, sa);
       } else {
-        launch_shadow(sc->walk, consumer_grid, stream, sa);
+        launch_shadow(sc->walk, sc->any_strata, consumer_grid, stream, sa);
       }
       HIP_TRY(hipGetLastError());
       if (kernel_timing) {

@@ -60,12 +60,16 @@ void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, v
           launch_trace_w<WALK_WIDE>(primary, uv, motion, grid, st, a));
 }
 
-void launch_shadow(int walk, unsigned grid, void *stream, const ShadowArgs &a) {
+template <bool STRATA> static void launch_shadow_t(int walk, unsigned grid, hipStream_t st, const ShadowArgs &a) {
+  BY_WALK(walk, hipLaunchKernelGGL((k_shadow<WALK_PACKET, STRATA>), dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL((k_shadow<WALK_LANE, STRATA>), dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL((k_shadow<WALK_ORDERED, STRATA>), dim3(grid), dim3(256), 0, st, a),
+          hipLaunchKernelGGL((k_shadow<WALK_WIDE, STRATA>), dim3(grid), dim3(256), 0, st, a));
+}
+void launch_shadow(int walk, bool strata, unsigned grid, void *stream, const ShadowArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  BY_WALK(walk, hipLaunchKernelGGL(k_shadow<WALK_PACKET>, dim3(grid), dim3(256), 0, st, a),
-          hipLaunchKernelGGL(k_shadow<WALK_LANE>, dim3(grid), dim3(256), 0, st, a),
-          hipLaunchKernelGGL(k_shadow<WALK_ORDERED>, dim3(grid), dim3(256), 0, st, a),
-          hipLaunchKernelGGL(k_shadow<WALK_WIDE>, dim3(grid), dim3(256), 0, st, a));
+  if (strata) launch_shadow_t<true>(walk, grid, st, a);
+  else launch_shadow_t<false>(walk, grid, st, a);
 }
 
 template <bool PRIMARY, bool UV, bool MOTION>

@@ -1307,7 +1307,8 @@ __global__ __launch_bounds__(256) void k_shade(const TraceArgs a) {
 }
 
 
-// Raytracer::compute_shadow (Raytracer.cpp:145-208) for one (hit, light) pair per lane.  Each lane
+// Raytracer::compute_shadow (Raytracer.cpp:145-208) for one (hit, light) pair per lane: the form used
+// when every light of the frame has a single stratum (no area light is sampled more than once).  Each lane
 // is a small state machine -- stratum index, distance walked, attenuation -- and the wave runs
 // closest-hit segments until every lane is done, so lanes with many strata or glass on the way do
 // not hold the others idle between their segments.  Shadow rays are at shutter time 0.5 (Ray.h:15).
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_shade(const TraceArgs a) {
 // key, light) stay in memory: the traversal with its inlined intersectors sets the kernel's vector
 // register peak, and every register freed there counts towards one more resident wave per SIMD.
 template <int WALK>
-DEV void shadow_block(const ShadowArgs &a, const LightTable &lights, bool valid, size_t slot, unsigned &n_node,
+DEV void shadow_block_items(const ShadowArgs &a, const LightTable &lights, bool valid, size_t slot, unsigned &n_node,
                       unsigned &n_prim, unsigned &n_seg) {
   // per lane: the item (point, colour, key, pixel, light) and the walk state
   __shared__ double park_p[3][256], park_c[3][256], park_w[4][256];  // park_w: total att cur dist
@@ -1430,8 +1431,183 @@ DEV void shadow_block(const ShadowArgs &a, const LightTable &lights, bool valid,
 #endif
 }
 
-// Fixed-size grid striding over the virtual blocks of the shadow queue.
+// Raytracer::compute_shadow (Raytracer.cpp:145-208) for the 64 (hit, light) items of a wave, when some
+// light of the frame has more than one stratum.
+//
+// An item has side x side strata (one for a point light), each a chain of closest-hit segments that
+// goes on through transparent objects.  The unit of work handed to a lane is one stratum of one item:
+// the wave numbers its items' strata 0 .. N - 1 and a lane that has finished a stratum takes the next
+// number nobody has taken, between two segments.  (One lane per item, strata one after the other, kept
+// 33 of 64 lanes busy on a scene of area lights seen through glass: the lanes whose strata cross more
+// surfaces held the wave.)  A stratum's 1 - attenuation is added to its item's sum in LDS; the lane
+// that finishes an item's last stratum adds contribution x (1 - shadow) to the pixel
+// (Raytracer.cpp:264-271).  The strata of an item are therefore summed in the order they finish, not
+// in index order: the terms are 0 or 1 unless glass attenuates, and then the sum can differ from the
+// reference's in its last bit.  Shadow rays are at shutter time 0.5 (Ray.h:15).
+//
+// While a segment is being traced, the lane's walk state that the traversal does not touch is
+// parked in LDS and the item (point, colour, pixel, random key, light) stays there throughout: the
+// traversal with its inlined intersectors sets the kernel's vector register peak, and every register
+// freed there counts towards one more resident wave per SIMD.
 template <int WALK>
+DEV void shadow_block_strata(const ShadowArgs &a, const LightTable &lights, bool valid, size_t slot, unsigned &n_node,
+                      unsigned &n_prim, unsigned &n_seg) {
+  // per item (indexed by the lane that loaded it)
+  __shared__ double park_p[3][256], park_c[3][256], park_sum[256];
+  __shared__ uint64_t park_key[256];
+  __shared__ uint32_t park_pixel[256], park_light[256], park_first[256];
+  __shared__ int32_t park_left[256];
+  // per lane: the walk state of the stratum in hand (att cur dist)
+  __shared__ double park_w[3][256];
+  const DScene &sc = a.sc;
+  const mirt_config &cfg = a.fr.cfg;
+  const int tid = threadIdx.x, lane = tid & 63, w0 = tid & ~63;
+#if MIRT_PROFILE == 2
+  PROF_DECL;
+#endif
+  int n_mine = 0;
+  if (valid) {
+    const DShadowItem it = a.items[slot];
+    park_p[0][tid] = it.p[0];
+    park_p[1][tid] = it.p[1];
+    park_p[2][tid] = it.p[2];
+    park_c[0][tid] = it.c[0];
+    park_c[1][tid] = it.c[1];
+    park_c[2][tid] = it.c[2];
+    park_key[tid] = it.key;
+    park_pixel[tid] = it.pixel;
+    park_light[tid] = it.light;
+    const int side = light_side(lights, a.fr, it.light);
+    n_mine = side * side;
+  }
+  park_sum[tid] = 0.0;
+  park_left[tid] = n_mine;
+  // number the wave's strata: item j owns first[j] .. first[j] + n_j - 1
+  int incl = n_mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if (lane >= d) incl += v;
+  }
+  park_first[tid] = (uint32_t)(incl - n_mine);
+  const int N = __shfl(incl, 63);
+  // every item the same power-of-two number of strata (the usual case): the item is a shift away
+  const int n0 = __builtin_amdgcn_readfirstlane(n_mine);
+  const bool uniform = n0 > 0 && (n0 & (n0 - 1)) == 0 && __ballot(n_mine != n0) == 0;
+  const int shift = uniform ? __ffs(n0) - 1 : 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  PARK_FENCE();
+
+  // the stratum is over: its term goes to the item; the lane that brings an item's last term finishes it
+  const bool single = uniform && n0 == 1;  // one stratum per item (point lights): its term is the item's sum
+  auto stratum_done = [&](int it, double term) {
+    if (!single && term != 0.0) atomicAdd(&park_sum[it], term);
+    if (single || atomicSub(&park_left[it], 1) == 1) {
+      const double shadow = (single ? term : park_sum[it]) * light_inv_n(lights, a.fr, park_light[it]);
+      if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
+        pixel_add(a.accum, a.fr.plane, park_pixel[it], mk(park_c[0][it], park_c[1][it], park_c[2][it]) * (1.0 - shadow));
+    }
+  };
+
+  int it = -1;  // the item (index into the parked arrays) whose stratum this lane walks; < 0: none
+  int next = 0; // the first stratum number nobody has taken (wave-uniform)
+  double att = 1.0, cur = 0.0, dist = 0.0, eps = 0.0;
+  d3 dir = mk(0, 0, 1), P = mk(0, 0, 0);
+#if MIRT_PROFILE == 2
+  PROF_MARK(0);
+#endif
+  for (;;) {
+    // ---- lanes without a stratum take the next numbers ----------------------------------------------
+    const bool idle = it < 0;
+    const unsigned long long im = __ballot(idle);
+    if (im != 0 && next < N) {
+      const int id = next + (int)__popcll(im & below);
+      if (idle && id < N) {
+        int j;
+        if (uniform) {
+          j = id >> shift;
+        } else {
+          j = 0;
+#pragma unroll
+          for (int step = 32; step; step >>= 1)
+            if (park_first[w0 + j + step] <= (uint32_t)id) j += step;
+        }
+        it = w0 + j;
+        const int st = id - (int)park_first[it];
+        const uint32_t li = park_light[it];
+        P = mk(park_p[0][it], park_p[1][it], park_p[2][it]);
+        eps = cfg.ray_offset_epsilon;
+        if (cfg.use_adaptive_epsilon) eps += len(P) * cfg.adaptive_epsilon_scale;
+        const d3 to = stratum_point(lights, sc, a.fr, li, park_key[it], st, light_side(lights, a.fr, li)) - P;
+        dist = len(to);
+        dir = to / dist;
+        att = 1.0;
+        cur = eps;
+        if (!(cur < dist)) {  // nothing to walk: this stratum is unoccluded
+          stratum_done(it, 0.0);
+          it = -1;
+        }
+      }
+      next += (int)__popcll(im);
+    }
+    const bool busy = it >= 0;
+    if (!__any(busy)) {
+      if (next >= N) break;
+      continue;
+    }
+    // ---- one segment -----------------------------------------------------------------------------
+    const RayL ray = make_ray(P + dir * cur, dir, 0.5);
+    double closest = dist - cur;
+    Best<false> best;  // shadow segments record no hit point
+    best.rec = nullptr;
+    best.prim = -1;
+    best.t = 0;
+    if (busy) n_seg++;
+    park_w[0][tid] = att;
+    park_w[1][tid] = cur;
+    park_w[2][tid] = dist;
+    PARK_FENCE();
+#if MIRT_PROFILE == 2
+    PROF_MARK(2);
+#endif
+    traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+#if MIRT_PROFILE == 2
+    PROF_MARK(1);
+#endif
+    PARK_FENCE();
+    att = park_w[0][tid];
+    cur = park_w[1][tid];
+    dist = park_w[2][tid];
+    dir = ray.d;
+    if (busy) {
+      P = mk(park_p[0][it], park_p[1][it], park_p[2][it]);
+      bool done = true;
+      if (best.prim >= 0 && best.t < (dist - cur)) {
+        const double tr = sc.prim_transparency[best.prim];
+        if (tr > 0.0) {
+          const double opacity = 1.0 - tr;
+          att *= (1.0 - opacity);
+          cur += best.t + eps;
+          done = (att < 0.01) || !(cur < dist);
+        } else {
+          att = 0.0;
+        }
+      }
+      if (done) {
+        stratum_done(it, 1.0 - att);
+        it = -1;
+      }
+    }
+  }
+#if MIRT_PROFILE == 2
+  PROF_MARK(3);
+  PROF_FLUSH(my_counters(a.counters));
+#endif
+}
+
+// Fixed-size grid striding over the virtual blocks of the shadow queue.
+// STRATA: some light of the frame has more than one stratum.
+template <int WALK, bool STRATA>
 __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
   __shared__ LightTable lights;
@@ -1440,7 +1616,8 @@ __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k
   for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
     size_t slot;
     const bool valid = view_entry(v, vb, a.shard_cap, slot);
-    shadow_block<WALK>(a, lights, valid, slot, n_node, n_prim, n_seg);
+    if (STRATA) shadow_block_strata<WALK>(a, lights, valid, slot, n_node, n_prim, n_seg);
+    else shadow_block_items<WALK>(a, lights, valid, slot, n_node, n_prim, n_seg);
   }
 #ifndef MIRT_PROFILE
   count_add(&my_counters(a.counters)->shadow_node_tests, n_node);
