@@ -23,7 +23,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -Iinclude -I$(CSRC) -Wal
             -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden $(EXTRA_HIPFLAGS)
 # no FMA contraction on the host: the matrices and boxes computed here are compared bit for bit
 # with the reference's
-HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra -Iinclude -I$(HOST)
+HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -pthread -Wall -Wextra -Iinclude -I$(HOST)
 
 .PHONY: all engine host cli oracle clean test-all benchmark $(addprefix test-,1 2 3 4 5 6 7)
 all: engine host cli oracle

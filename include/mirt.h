@@ -247,14 +247,16 @@ int mirt_trace_rays(mirt_scene *scene, int64_t n, const double *origin, const do
                     const double *time, double t_min, const double *t_max, int32_t *prim_id, double *t,
                     double *normal);
 
-/* mirt_render_tiles in two halves, so that a caller can keep two frames in flight (no counterpart in
- * the reference, which renders one frame per process run).  _begin enqueues the whole frame on
- * `stream` (NULL: the scene's own) using working-memory set `slot` (0 or 1) and returns without
+/* mirt_render_tiles in two halves, so that a caller can keep several frames in flight (no counterpart
+ * in the reference, which renders one frame per process run).  _begin enqueues the whole frame on
+ * `stream` (NULL: the scene's own) using working-memory set `slot` (0 .. MIRT_SLOTS - 1; a set's
+ * queues are allocated when it is first used) and returns without
  * waiting; d_rgb_out is complete when the work enqueued on `stream` has run, so work the caller
  * enqueues on the same stream afterwards (a gather, a copy) sees the frame.  _end waits for the
  * slot's frame and fills *stats.  If a ray queue overflowed, _end renders the frame again with finer
  * launches before it returns (stats->frame_attempts > 1): whatever the caller enqueued behind _begin
  * then read an incomplete frame and has to be redone.  A slot holds one frame at a time. */
+#define MIRT_SLOTS 4
 int mirt_render_tiles_begin(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
                             int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
                             double *d_rgb_out, void *stream, int slot);

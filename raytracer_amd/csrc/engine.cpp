@@ -167,7 +167,7 @@ struct mirt_scene {
       for (auto e : events) (void)hipEventDestroy(e);
       if (pinned) (void)hipHostFree(pinned);
     }
-  } work[2], fixed_work;
+  } work[MIRT_SLOTS], fixed_work;
   char *scratch = nullptr;  // device address of this GPU's static array (scratch_address)
   std::vector<DLightFrame> light_frame_host;
   DeviceBuffer out, ids;
@@ -1250,12 +1250,12 @@ int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
 int begin_frame(mirt_scene *sc, int slot, const mirt_camera *camera, const mirt_config *config, int width, int height,
                 int spp, int tile_w, int tile_h, int rank, int world, double *d_out, hipStream_t stream) {
   if (!sc || !camera || !config || !d_out) return fail(MIRT_ERR_INVALID, "NULL argument");
-  if (slot < 0 || slot > 2) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
+  if (slot < -1 || slot >= MIRT_SLOTS) return fail(MIRT_ERR_INVALID, "slot must be 0 .. %d", MIRT_SLOTS - 1);
   if (width <= 0 || height <= 0 || spp <= 0) return fail(MIRT_ERR_INVALID, "width, height and spp must be positive");
   if (tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world)
     return fail(MIRT_ERR_INVALID, "bad tile split: tile %dx%d rank %d of %d", tile_w, tile_h, rank, world);
   if ((double)width * height * spp > 4.0e9) return fail(MIRT_ERR_UNSUPPORTED, "more than 4e9 samples in one frame");
-  mirt_scene::WorkSet *ws = slot == 2 ? &sc->fixed_work : &sc->work[slot];  // 2: the set that never allocates
+  mirt_scene::WorkSet *ws = slot < 0 ? &sc->fixed_work : &sc->work[slot];  // -1: the set that never allocates
   if (ws->pending) return fail(MIRT_ERR_INVALID, "slot %d still holds a frame: call mirt_render_tiles_end first", slot);
   HIP_TRY(hipSetDevice(sc->device));
   (void)hipGetLastError();  // an error some earlier, failed call left behind is not this frame's
@@ -1294,14 +1294,14 @@ int render_device(mirt_scene *sc, const mirt_camera *camera, const mirt_config *
 MIRT_API int mirt_render_tiles_begin(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
                                      int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
                                      double *d_rgb_out, void *stream, int slot) {
-  if (slot < 0 || slot > 1) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
+  if (slot < 0 || slot >= MIRT_SLOTS) return fail(MIRT_ERR_INVALID, "slot must be 0 .. %d", MIRT_SLOTS - 1);
   return begin_frame(scene, slot, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
                      static_cast<hipStream_t>(stream));
 }
 
 MIRT_API int mirt_render_tiles_end(mirt_scene *scene, int slot, mirt_stats *stats) {
   if (!scene) return fail(MIRT_ERR_INVALID, "NULL scene");
-  if (slot < 0 || slot > 1) return fail(MIRT_ERR_INVALID, "slot must be 0 or 1");
+  if (slot < 0 || slot >= MIRT_SLOTS) return fail(MIRT_ERR_INVALID, "slot must be 0 .. %d", MIRT_SLOTS - 1);
   HIP_TRY(hipSetDevice(scene->device));
   return finish_frame(scene, &scene->work[slot], stats);
 }
@@ -1316,7 +1316,7 @@ MIRT_API int mirt_render_tiles(mirt_scene *scene, const mirt_camera *camera, con
 MIRT_API int mirt_render_tiles_noalloc(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config,
                                        int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
                                        double *d_rgb_out, void *stream, mirt_stats *stats) {
-  if (int rc = begin_frame(scene, 2, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
+  if (int rc = begin_frame(scene, -1, camera, config, width, height, spp, tile_w, tile_h, rank, world, d_rgb_out,
                            static_cast<hipStream_t>(stream)))
     return rc;
   return finish_frame(scene, &scene->fixed_work, stats);

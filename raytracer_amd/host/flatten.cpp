@@ -13,10 +13,13 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <thread>
+#include <utility>
 
 namespace {
 
@@ -35,13 +38,25 @@ struct Builder {
   std::vector<Point> centres;      // per primitive, split key
   std::vector<int32_t> order;      // primitive indices, partitioned in place
   FlatScene *out = nullptr;
+  // nodes in the subtree over n objects at depth d: the split rule depends on n and d only, so every
+  // node's index in depth-first order is known before its subtree is built
+  std::map<std::pair<int, int>, int32_t> sizes;
 
-  int32_t build(int lo, int hi, int depth) {
-    const int32_t me = static_cast<int32_t>(out->nodes.size());
-    out->nodes.emplace_back();
-    out->node_count++;
-    out->max_depth = std::max(out->max_depth, depth + 1);
+  int32_t subtree_nodes(int n, int depth) {
+    if (n <= kMaxLeafSize || depth >= kMaxDepth) return 1;
+    const auto key = std::make_pair(n, depth);
+    const auto it = sizes.find(key);
+    if (it != sizes.end()) return it->second;
+    const int mid = n / 2;
+    const int32_t v = 1 + subtree_nodes(mid, depth + 1) + subtree_nodes(n - mid, depth + 1);
+    sizes[key] = v;
+    return v;
+  }
 
+  // Builds the subtree of order[lo, hi) into nodes[me ...] (already allocated); returns its depth.
+  // The two halves of a split touch disjoint ranges of `order` and of `nodes`: on large scenes the top
+  // `fork` levels build them on two threads each.
+  int build(int lo, int hi, int depth, int32_t me, int fork) {
     BoundingBox box{Point(0, 0, 0), Point(0, 0, 0)};
     for (int i = lo; i < hi; ++i) {
       if (i == lo) box = boxes[order[i]];
@@ -56,18 +71,41 @@ struct Builder {
     const int n = hi - lo;
     if (n <= kMaxLeafSize || depth >= kMaxDepth) {
       fill(-1, -1, lo, n);
-      out->leaf_count++;
-      return me;
+      return 1;
     }
     const Vec3 ext = box.max - box.min;
     const int axis = (ext.x > ext.y && ext.x > ext.z) ? 0 : (ext.y > ext.z ? 1 : 2);
     const int mid = n / 2;  // n >= 3, so both halves are non-empty
     std::nth_element(order.begin() + lo, order.begin() + lo + mid, order.begin() + hi,
                      [this, axis](int32_t a, int32_t b) { return centres[a][axis] < centres[b][axis]; });
-    const int32_t left = build(lo, lo + mid, depth + 1);
-    const int32_t right = build(lo + mid, hi, depth + 1);
+    const int32_t left = me + 1, right = left + sizes_at(mid, depth + 1);
+    int dl = 0, dr = 0;
+    if (fork > 0) {
+      std::thread t([&] { dl = build(lo, lo + mid, depth + 1, left, fork - 1); });
+      dr = build(lo + mid, hi, depth + 1, right, fork - 1);
+      t.join();
+    } else {
+      dl = build(lo, lo + mid, depth + 1, left, 0);
+      dr = build(lo + mid, hi, depth + 1, right, 0);
+    }
     fill(left, right, 0, 0);
-    return me;
+    return 1 + std::max(dl, dr);
+  }
+  int32_t sizes_at(int n, int depth) const {  // read-only once run() has filled the table
+    if (n <= kMaxLeafSize || depth >= kMaxDepth) return 1;
+    return sizes.at(std::make_pair(n, depth));
+  }
+
+  void run() {
+    const int total = static_cast<int>(order.size());
+    const int32_t n_nodes = subtree_nodes(total, 0);
+    out->nodes.assign(static_cast<std::size_t>(n_nodes), mirt_node{});
+    int fork = total >= 65536 ? 4 : 0;  // 16 threads at the fourth level
+    if (const char *e = std::getenv("MIRT_BVH_FORK_LEVELS")) fork = std::max(0, std::min(6, std::atoi(e)));
+    out->max_depth = build(0, total, 0, 0, fork);
+    out->node_count = n_nodes;
+    out->leaf_count = 0;
+    for (const mirt_node &n : out->nodes) out->leaf_count += n.left < 0 ? 1 : 0;
   }
 };
 
@@ -252,8 +290,7 @@ FlatScene flatten_scene(const Scene &scene, const std::string &texture_root) {
 
   b.order.resize(total);
   for (std::size_t i = 0; i < total; ++i) b.order[i] = static_cast<int32_t>(i);
-  fs.nodes.reserve(total ? 2 * total : 1);
-  b.build(0, static_cast<int>(total), 0);  // an empty scene still gets its one empty leaf
+  b.run();  // an empty scene still gets its one empty leaf
   fs.leaf_prims = std::move(b.order);
 
   for (const auto &l : scene.lights) {

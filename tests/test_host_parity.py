@@ -170,3 +170,26 @@ def test_synthetic_scene_is_deterministic_and_round_trips(tmp_path):
     a.write_ascii(path)
     D1 = arrays(HostScene(path, str(tmp_path)))
     assert all(np.array_equal(A1[k], D1[k]) for k in A1)
+
+
+def test_threaded_bvh_build_gives_the_same_tree(monkeypatch):
+    """Above 65536 primitives the host builds the two halves of the top splits on separate threads;
+    every node's depth-first index is known beforehand, so the arrays must not depend on it."""
+    import ctypes as C
+
+    from raytracer_amd import HostScene
+    from raytracer_amd import _abi as A
+
+    def tree(hs):
+        d = hs.desc
+        nodes = np.ctypeslib.as_array(C.cast(d.nodes, C.POINTER(C.c_uint8)), shape=(d.n_nodes * C.sizeof(A.Node),)).copy()
+        return nodes, np.ctypeslib.as_array(d.leaf_prims, shape=(d.n_leaf_prims,)).copy(), hs.bvh_stats()
+
+    monkeypatch.setenv("MIRT_BVH_FORK_LEVELS", "0")
+    n0, l0, s0 = tree(HostScene.synthetic(70001, 3))
+    monkeypatch.setenv("MIRT_BVH_FORK_LEVELS", "4")
+    n4, l4, s4 = tree(HostScene.synthetic(70001, 3))
+    monkeypatch.delenv("MIRT_BVH_FORK_LEVELS")
+    nd, ld, sd = tree(HostScene.synthetic(70001, 3))
+    assert np.array_equal(n0, n4) and np.array_equal(l0, l4) and s0 == s4
+    assert np.array_equal(n0, nd) and np.array_equal(l0, ld) and s0 == sd
