@@ -175,7 +175,7 @@ class DeviceScene:
 
     def render_tiles_begin(self, camera, config, width, height, spp, tile_w, tile_h, rank, world, out_ptr, stream,
                            slot):
-        """Enqueues this rank's tiles on `stream` with working-memory set `slot` (0 or 1) and returns
+        """Enqueues this rank's tiles on `stream` with working-memory set `slot` (0 .. 3) and returns
         without waiting (mirt_render_tiles_begin)."""
         _check(self._lib.mirt_render_tiles_begin(self._h, C.byref(camera), C.byref(config), width, height, spp,
                                                  tile_w, tile_h, rank, world, C.c_void_p(out_ptr),

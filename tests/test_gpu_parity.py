@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from conftest import GOLDEN, SCENES, SYNTHETIC
+from conftest import FIXTURES, GOLDEN, SCENES, SYNTHETIC
 from raytracer_amd import default_config
 
 pytestmark = pytest.mark.gpu
@@ -277,6 +277,35 @@ def test_edge_cases(host_scenes, device_scenes, tmp_path):
         ds.render(cam, default_config(), 0, 10, 1)
     with pytest.raises(MirtError):
         ds.render(cam, default_config(), 10, 10, 0)
+
+
+def test_mixed_point_and_area_lights(tmp_path):
+    """Shadow items of one wave with different numbers of strata (a point light: 1, area lights with 16,
+    9 and 4 samples): the wave numbers them with a prefix sum and finds a stratum's item by search, a path
+    no bundled scene takes (their lights are all of one kind).  Test6 with its lights edited."""
+    from raytracer_amd import DeviceScene, HostScene
+    text = open(os.path.join(FIXTURES, "ASCII", "Test6.txt")).read().split("\n")
+    kinds = [i for i, l in enumerate(text) if l.startswith("light_type AREA")]
+    samples = [i for i, l in enumerate(text) if l.startswith("samples ")]
+    assert len(kinds) == 5 and len(samples) == 5
+    text[kinds[1]] = "light_type POINT"
+    for i, n in zip(samples, (16, 1, 9, 4, 16)):
+        text[i] = f"samples {n}"
+    (tmp_path / "ASCII").mkdir()
+    path = tmp_path / "ASCII" / "Mixed.txt"
+    path.write_text("\n".join(text))
+    hs = HostScene(str(path), os.path.join(FIXTURES, ""))
+    ds = DeviceScene(hs, 0)
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=4)  # shadow_samples left at 0: every light keeps its own count
+    for traversal in ("packet", "lane"):
+        ds.set_traversal(traversal)
+        ref, ost = O.render(hs.desc, cam, cfg, 160, 90, 4, O.RNG_KEYED)
+        got, st = ds.render(cam, cfg, 160, 90, 4)
+        p, mae = O.psnr(got, ref), float(np.abs(got - ref).mean())
+        print(f"mixed lights, {traversal}: PSNR {p:.1f} dB, MAE {mae:.3e}, segments {st['shadow_segments']} / {ost['shadow_segments']}")
+        assert st["shadow_segments"] <= ost["shadow_segments"] and st["shadow_segments"] >= 0.9 * ost["shadow_segments"]
+        assert p >= 60.0 and mae <= 1e-6
 
 
 def crop_vs_oracle(ds, hs, cam, cfg, width, height, spp, windows, frame=None, min_psnr=60.0, max_mae=1e-6):
