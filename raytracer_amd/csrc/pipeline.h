@@ -952,16 +952,38 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
   // First pass counts the wave's items so that ONE atomic reserves room for all of them; it decides
   // "faces the light" on the un-normalised direction (same sign as the reference's N.L up to the last
   // rounding of a product that is then of the order of 1e-16 anyway) and the second pass keeps to it.
+  //
+  // The rays this wave is going to append (mirror, every glossy-lobe sample, Fresnel reflection,
+  // refraction) are counted here too, and the two reservations -- shadow items, rays -- are issued
+  // together: each is an atomic whose result the wave has to wait for, and one wait covers both.
+  const bool refl = spawn && hit && R > 0.0 && !pass;
+  // a lane without a hit has no material: `m` is only read behind `refl`
+  int samples = 1;
+  if (refl && cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
+  const bool mirror = samples == 1 || (refl && m.glossiness > 0.94);
+  const bool push_mirror = refl && mirror, lobe = refl && !mirror;  // a lobe lane appends glossy_samples rays
+  const bool push_reflect = spawn && hit && glass, push_refract = spawn && hit && glass && !tir;
+  const unsigned long long m_mirror = __ballot(push_mirror), m_lobe = __ballot(lobe), m_reflect = __ballot(push_reflect),
+                           m_refract = __ballot(push_refract);
+  const uint32_t n_mirror = (uint32_t)__popcll(m_mirror), n_lobe = (uint32_t)__popcll(m_lobe),
+                 n_reflect = (uint32_t)__popcll(m_reflect), n_refract = (uint32_t)__popcll(m_refract);
+  const uint32_t n_samples = (uint32_t)cfg.glossy_samples;
+  const uint32_t total = n_mirror + n_lobe * n_samples + n_reflect + n_refract;
+  uint32_t ray_base = 0;
   {
-    uint32_t total = 0;
+    uint32_t items = 0;
     for (int li = 0; li < sc.n_lights; li++) {
       const bool push = hit && lit && dot(sn, ld3(rdonly(sc.lights)[li].location) - sf.p) > 0.0;
-      total += (uint32_t)__popcll(__ballot(push));
+      items += (uint32_t)__popcll(__ballot(push));
     }
-    if (total) {
-      uint32_t base = 0;
-      if (__lane_id() == 0) base = atomicAdd(a.shadow_count + shard * QUEUE_COUNT_STRIDE, total);
-      base = __shfl(base, 0);
+    uint32_t base = 0;
+    if (__lane_id() == 0) {
+      if (items) base = atomicAdd(a.shadow_count + shard * QUEUE_COUNT_STRIDE, items);
+      if (total) ray_base = atomicAdd(a.out_count + shard * QUEUE_COUNT_STRIDE, total);
+    }
+    base = __shfl(base, 0);
+    ray_base = __shfl(ray_base, 0);
+    if (items) {
       const unsigned long long below = (1ull << __lane_id()) - 1ull;
       for (int li = 0; li < sc.n_lights; li++) {
         const RO mirt_light &L = rdonly(sc.lights)[li];
@@ -992,24 +1014,11 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
   if (!spawn) return;  // wave-uniform
 
   // ---- children: reflection (Raytracer.cpp:317-411; dropped when the glass branch returns `combined`),
-  // Fresnel reflection and refraction (Raytracer.cpp:414-464).  The wave first counts all the rays it
-  // is going to append, reserves room for them with one atomic, then writes them kind by kind.
-  const bool refl = hit && R > 0.0 && !pass;
-  // a lane without a hit has no material: `m` is only read behind `refl`
-  int samples = 1;
-  if (refl && cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
-  const bool mirror = samples == 1 || (refl && m.glossiness > 0.94);
-  const bool push_mirror = refl && mirror, lobe = refl && !mirror;  // a lobe lane appends glossy_samples rays
-  const bool push_reflect = hit && glass, push_refract = hit && glass && !tir;
-  const unsigned long long m_mirror = __ballot(push_mirror), m_lobe = __ballot(lobe), m_reflect = __ballot(push_reflect),
-                           m_refract = __ballot(push_refract);
-  const uint32_t n_mirror = (uint32_t)__popcll(m_mirror), n_lobe = (uint32_t)__popcll(m_lobe),
-                 n_reflect = (uint32_t)__popcll(m_reflect), n_refract = (uint32_t)__popcll(m_refract);
-  const uint32_t n_samples = (uint32_t)cfg.glossy_samples;
-  const uint32_t total = n_mirror + n_lobe * n_samples + n_reflect + n_refract;
+  // Fresnel reflection and refraction (Raytracer.cpp:414-464), written kind by kind into the room
+  // reserved above.
   if (total) {
     const unsigned long long below = (1ull << __lane_id()) - 1ull;
-    uint32_t at = queue_reserve(a.out_count, shard, total);
+    uint32_t at = ray_base;
     const d3 r = reflect_dir(ray.d, sn);
     const bool metal = R > 0.5 && T < 0.1;
     d3 cw = ws * R;
