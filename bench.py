@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--glossy-reflection", type=int, default=None)
     ap.add_argument("--depth-of-field", type=float, nargs=2, default=None, metavar=("FSTOP", "FOCUS"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, choices=(1, 2), default=2)
+    ap.add_argument("--frames-in-flight", type=int, choices=(1, 2, 3, 4), default=2)
     args = ap.parse_args()
     for k, v in PRESETS[args.config].items():
         if getattr(args, k) is None:
