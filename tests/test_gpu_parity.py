@@ -308,6 +308,43 @@ def test_mixed_point_and_area_lights(tmp_path):
         assert p >= 60.0 and mae <= 1e-6
 
 
+def test_more_lights_than_the_light_table_holds(tmp_path):
+    """The shadow kernels keep the first 32 lights' positions and strata in LDS and read the others from
+    memory.  Test1 with 40 point lights (and, second, with every fourth one an area light of 4 samples):
+    lights on both sides of the limit, in both forms of the shadow kernel."""
+    import random
+    from raytracer_amd import DeviceScene, HostScene
+    text = open(os.path.join(FIXTURES, "ASCII", "Test1.txt")).read().split("\n")
+    start = text.index("LIGHTS 2")
+    end = next(i for i in range(start + 1, len(text)) if text[i].startswith("SPHERES"))
+    rnd = random.Random(7)
+    (tmp_path / "ASCII").mkdir()
+    for variant in ("point", "mixed"):
+        lights = ["LIGHTS 40"]
+        for i in range(40):
+            area = variant == "mixed" and i % 4 == 3
+            lights += [f"name L{i}", f"location {rnd.uniform(-1, 2):.6f} {rnd.uniform(-1, 2):.6f} {rnd.uniform(1.2, 2.5):.6f}",
+                       "intensity 0.6", f"color {rnd.uniform(0.3, 1):.4f} {rnd.uniform(0.3, 1):.4f} {rnd.uniform(0.3, 1):.4f}"]
+            if area:
+                lights += ["light_type AREA", "area_shape RECTANGLE", "area_size 0.4 0.3", "normal 0.0 0.0 -1.0", "samples 4",
+                           "cast_shadows 1", "shadow_soft_size 0.0"]
+            else:
+                lights += ["light_type POINT", "cast_shadows 1", "shadow_soft_size 0.0"]
+        path = tmp_path / "ASCII" / f"Lights40_{variant}.txt"
+        path.write_text("\n".join(text[:start] + lights + text[end:]))
+        hs = HostScene(str(path), os.path.join(FIXTURES, ""))
+        assert hs.desc.n_lights == 40
+        ds = DeviceScene(hs, 0)
+        cam, _ = hs.camera(0)
+        cfg = default_config(max_ray_depth=3)
+        ref, ost = O.render(hs.desc, cam, cfg, 128, 96, 2, O.RNG_KEYED)
+        got, st = ds.render(cam, cfg, 128, 96, 2)
+        p, mae = O.psnr(got, ref), float(np.abs(got - ref).mean())
+        print(f"40 lights ({variant}): PSNR {p:.1f} dB, MAE {mae:.3e}, segments {st['shadow_segments']} / {ost['shadow_segments']}")
+        assert st["shadow_segments"] > 0 and st["shadow_segments"] <= ost["shadow_segments"]
+        assert p >= 60.0 and mae <= 1e-6
+
+
 def crop_vs_oracle(ds, hs, cam, cfg, width, height, spp, windows, frame=None, min_psnr=60.0, max_mae=1e-6):
     """Renders the full frame on the GPU and compares windows of it, pixel by pixel, with the oracle's
     render of the same windows (same pixel keys, so a window is a crop of the oracle's full frame)."""
