@@ -308,6 +308,54 @@ def test_mixed_point_and_area_lights(tmp_path):
         assert p >= 60.0 and mae <= 1e-6
 
 
+@pytest.mark.parametrize("name", ["Test1", "Test5"])
+def test_caller_supplied_tree_with_large_leaves(name, host_scenes):
+    """The C ABI takes any depth-first tree, not only the two-per-leaf one the host builder makes: the
+    same scene with a three-node tree whose two leaves hold half of the primitives each (the wide walk
+    keeps such leaves as index ranges, the others loop over them) must give the hits of the full tree
+    -- the closest hit does not depend on the tree, ties aside -- and the oracle's on the same tree."""
+    import ctypes as C
+
+    from raytracer_amd import DeviceScene
+    from raytracer_amd import _abi as A
+    hs = host_scenes(name)
+    d = hs.desc
+    root = d.nodes[0]
+    assert root.left == 1 and root.right > 1
+    left, right = d.nodes[root.left], d.nodes[root.right]
+
+    def first_leaf(i):
+        while d.nodes[i].left >= 0:
+            i = d.nodes[i].left
+        return d.nodes[i].first
+
+    k = first_leaf(root.right)  # leaf_prims[0:k] is the left subtree's, the rest the right one's
+    nodes = (A.Node * 3)()
+    for j, (src, lo, cnt) in enumerate(((root, 0, 0), (left, 0, k), (right, k, d.n_leaf_prims - k))):
+        nodes[j].bmin, nodes[j].bmax = src.bmin, src.bmax
+        nodes[j].left, nodes[j].right, nodes[j].first, nodes[j].count = (1, 2, 0, 0) if j == 0 else (-1, -1, lo, cnt)
+    flat = type(d).from_buffer_copy(d)  # same arrays, another tree
+    flat.nodes = C.cast(nodes, C.POINTER(A.Node))
+    flat.n_nodes = 3
+    cam, _ = hs.camera(0)
+    ref = O.trace_ids(flat, cam, W, H)
+    full = O.trace_ids(d, cam, W, H)
+    assert float((ref["prim_id"] == full["prim_id"]).mean()) >= 0.999
+    ds = DeviceScene(flat, 0)
+    for traversal in ("packet", "lane", "ordered", "wide"):
+        ds.set_traversal(traversal)
+        got = ds.trace_ids(cam, W, H)
+        same = got["prim_id"] == ref["prim_id"]
+        print(f"{name}, two big leaves ({k} + {d.n_leaf_prims - k}), {traversal}: agreement {float(same.mean()):.6f}")
+        assert float(same.mean()) >= 0.9995
+        hit = same & (ref["prim_id"] >= 0)
+        assert np.allclose(got["t"][hit], ref["t"][hit], rtol=2e-5, atol=1e-9)
+    frame, st = ds.render(cam, default_config(max_ray_depth=3), W, H, 2)
+    want, _ = O.render(flat, cam, default_config(max_ray_depth=3), W, H, 2, O.RNG_KEYED)
+    assert O.psnr(frame, want) >= 60.0
+    ds.close()
+
+
 def test_more_lights_than_the_light_table_holds(tmp_path):
     """The shadow kernels keep the first 32 lights' positions and strata in LDS and read the others from
     memory.  Test1 with 40 point lights (and, second, with every fourth one an area light of 4 samples):
