@@ -51,7 +51,7 @@ $(BUILD)/multi.o: $(CSRC)/multi.cpp $(ENGINE_HDRS) Makefile | $(BUILD)
 $(BUILD)/engine_math.o: $(HOST)/mirt_math.cpp $(HOST)/mirt_math.h | $(BUILD)
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
 $(LIB)/libmirt.so: $(BUILD)/kernels.o $(BUILD)/engine.o $(BUILD)/multi.o $(BUILD)/engine_math.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl -pthread
 
 $(LIB)/libmirt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIB)/libmirt.so | $(LIB)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -L$(LIB) -lmirt -Wl,-rpath,'$$ORIGIN'

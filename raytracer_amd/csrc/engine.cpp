@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../host/mirt_math.h"
@@ -182,7 +183,16 @@ struct mirt_scene {
   int light_frame_for = 0;  // shadow_samples the device copy of the lights' strata was made for
   bool light_frame_valid = false;
   bool any_strata = false;  // some light of the current light-frame table has more than one stratum
+  // frame to a caller's host buffer: pinned staging memory and one event per piece (copy_frame_out)
+  static constexpr int kStagePieces = 4;
+  char *stage = nullptr;
+  size_t stage_bytes = 0;
+  hipEvent_t stage_done[kStagePieces] = {};
+
   ~mirt_scene() {
+    if (stage) (void)hipHostFree(stage);
+    for (hipEvent_t e : stage_done)
+      if (e) (void)hipEventDestroy(e);
     if (null_stream_mark) (void)hipEventDestroy(null_stream_mark);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1346,6 +1356,65 @@ MIRT_API int mirt_scene_progress(mirt_scene *scene, double *band_ms, int max_ban
   return (int)p.size() - 1;
 }
 
+namespace {
+// A finished frame from device memory to the caller's buffer, which is ordinary pageable memory (the
+// reference's Image).  A plain hipMemcpy into pageable memory runs at about 9 GB/s here: 5.5 ms for a
+// 1080p frame that took 6 ms to render.  So the frame goes to pinned staging memory in a few pieces
+// (DMA at link speed), and each piece is copied on by a thread of its own as soon as it has arrived.
+int copy_frame_out(mirt_scene *sc, void *dst, const void *src, size_t bytes) {
+  constexpr int kPieces = mirt_scene::kStagePieces;
+  if (bytes < ((size_t)4 << 20)) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return MIRT_OK;
+  }
+  if (sc->stage_bytes < bytes) {
+    if (sc->stage) (void)hipHostFree(sc->stage);
+    sc->stage = nullptr;
+    sc->stage_bytes = 0;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {  // no pinned memory to be had: the plain way
+      (void)hipGetLastError();
+      HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+      return MIRT_OK;
+    }
+    sc->stage = static_cast<char *>(p);
+    sc->stage_bytes = bytes;
+  }
+  for (hipEvent_t &e : sc->stage_done)
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const size_t piece = ((bytes + kPieces - 1) / kPieces + 4095) & ~(size_t)4095;
+  size_t off[kPieces + 1];
+  for (int k = 0; k <= kPieces; ++k) off[k] = std::min(bytes, (size_t)k * piece);
+  for (int k = 0; k < kPieces; ++k) {
+    if (off[k + 1] > off[k])
+      HIP_TRY(hipMemcpyAsync(sc->stage + off[k], static_cast<const char *>(src) + off[k], off[k + 1] - off[k],
+                             hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipEventRecord(sc->stage_done[k], sc->stream));
+  }
+  hipError_t err[kPieces] = {};
+  auto carry = [&](int k) {
+    err[k] = hipEventSynchronize(sc->stage_done[k]);
+    if (err[k] == hipSuccess && off[k + 1] > off[k])
+      std::memcpy(static_cast<char *>(dst) + off[k], sc->stage + off[k], off[k + 1] - off[k]);
+  };
+  std::thread helpers[kPieces - 1];
+  int started = 0;
+  try {
+    for (int k = 1; k < kPieces; ++k) {
+      helpers[k - 1] = std::thread(carry, k);
+      started = k;
+    }
+  } catch (const std::exception &) {  // no more threads to be had: this one carries the rest
+  }
+  carry(0);
+  for (int k = started + 1; k < kPieces; ++k) carry(k);
+  for (int k = 1; k <= started; ++k) helpers[k - 1].join();
+  for (int k = 0; k < kPieces; ++k)
+    if (err[k] != hipSuccess) return fail(MIRT_ERR_DEVICE, "frame read-back: %s", hipGetErrorString(err[k]));
+  return MIRT_OK;
+}
+}  // namespace
+
 MIRT_API int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
                          int height, int spp, double *rgb_out, mirt_stats *stats) {
   if (!scene || !rgb_out) return fail(MIRT_ERR_INVALID, "NULL argument");
@@ -1356,8 +1425,7 @@ MIRT_API int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mir
   if (int rc = render_device(scene, camera, config, width, height, spp, width, height, 0, 1, scene->out.as<double>(),
                              nullptr, stats))
     return rc;
-  HIP_TRY(hipMemcpy(rgb_out, scene->out.p, bytes, hipMemcpyDeviceToHost));
-  return MIRT_OK;
+  return copy_frame_out(scene, rgb_out, scene->out.p, bytes);
 }
 
 MIRT_API int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int width, int height, int32_t *prim_id,
