@@ -1356,12 +1356,13 @@ MIRT_API int mirt_scene_progress(mirt_scene *scene, double *band_ms, int max_ban
   return (int)p.size() - 1;
 }
 
-namespace {
 // A finished frame from device memory to the caller's buffer, which is ordinary pageable memory (the
 // reference's Image).  A plain hipMemcpy into pageable memory runs at about 9 GB/s here: 5.5 ms for a
 // 1080p frame that took 6 ms to render.  So the frame goes to pinned staging memory in a few pieces
 // (DMA at link speed), and each piece is copied on by a thread of its own as soon as it has arrived.
-int copy_frame_out(mirt_scene *sc, void *dst, const void *src, size_t bytes) {
+// Not part of the ABI; also used by the device group (multi.cpp).  `src` must be complete: the copy
+// runs on the scene's own stream.
+int mirt_copy_frame_out(mirt_scene *sc, void *dst, const void *src, size_t bytes) {
   constexpr int kPieces = mirt_scene::kStagePieces;
   if (bytes < ((size_t)4 << 20)) {
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
@@ -1413,7 +1414,6 @@ int copy_frame_out(mirt_scene *sc, void *dst, const void *src, size_t bytes) {
     if (err[k] != hipSuccess) return fail(MIRT_ERR_DEVICE, "frame read-back: %s", hipGetErrorString(err[k]));
   return MIRT_OK;
 }
-}  // namespace
 
 MIRT_API int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config *config, int width,
                          int height, int spp, double *rgb_out, mirt_stats *stats) {
@@ -1425,7 +1425,7 @@ MIRT_API int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mir
   if (int rc = render_device(scene, camera, config, width, height, spp, width, height, 0, 1, scene->out.as<double>(),
                              nullptr, stats))
     return rc;
-  return copy_frame_out(scene, rgb_out, scene->out.p, bytes);
+  return mirt_copy_frame_out(scene, rgb_out, scene->out.p, bytes);
 }
 
 MIRT_API int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int width, int height, int32_t *prim_id,

@@ -28,6 +28,7 @@
 #define MIRT_API extern "C" __attribute__((visibility("default")))
 
 int mirt_fail(int code, const char *fmt, ...);  // engine.cpp: sets mirt_last_error()
+int mirt_copy_frame_out(mirt_scene *sc, void *dst, const void *src, size_t bytes);  // engine.cpp: staged read-back
 
 namespace {
 
@@ -268,8 +269,8 @@ MIRT_API int mirt_group_render(mirt_group *g, const mirt_camera *camera, const m
   for (int i = 0; i < n; ++i) da.offset[i] = off[i];
   launch_deinterleave(static_cast<unsigned>((static_cast<size_t>(width) * height + 255) / 256), root.stream, da);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(rgb_out, g->frame, frame_bytes, hipMemcpyDeviceToHost, root.stream));
   HIP_TRY(hipStreamSynchronize(root.stream));
+  if (int rc = mirt_copy_frame_out(root.scene, rgb_out, g->frame, frame_bytes)) return rc;
   for (int i = 1; i < n; ++i) {  // the senders' streams (RCCL enqueued the sends there)
     HIP_TRY(hipSetDevice(g->m[i].device));
     HIP_TRY(hipStreamSynchronize(g->m[i].stream));
