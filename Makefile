@@ -48,9 +48,11 @@ $(BUILD)/engine.o: $(CSRC)/engine.cpp $(ENGINE_HDRS) $(HOST)/mirt_math.h Makefil
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
 $(BUILD)/multi.o: $(CSRC)/multi.cpp $(ENGINE_HDRS) Makefile | $(BUILD)
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
+$(BUILD)/bvh_device.o: $(CSRC)/bvh_device.cpp $(ENGINE_HDRS) Makefile | $(BUILD)
+	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
 $(BUILD)/engine_math.o: $(HOST)/mirt_math.cpp $(HOST)/mirt_math.h | $(BUILD)
 	$(CXX) $(ENGINE_HOSTFLAGS) -c -o $@ $<
-$(LIB)/libmirt.so: $(BUILD)/kernels.o $(BUILD)/engine.o $(BUILD)/multi.o $(BUILD)/engine_math.o
+$(LIB)/libmirt.so: $(BUILD)/kernels.o $(BUILD)/engine.o $(BUILD)/multi.o $(BUILD)/bvh_device.o $(BUILD)/engine_math.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl -pthread
 
 $(LIB)/libmirt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIB)/libmirt.so | $(LIB)

@@ -209,6 +209,52 @@ void mirt_config_defaults(mirt_config *cfg);
 int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out);
 void mirt_scene_destroy(mirt_scene *scene);
 
+/* Where the BVH comes from.  The reference builds it on the host (build_bvh, Bvh.cpp:194-242) and so does
+ * MIRT_BUILDER_HOST: `desc->nodes` is that tree, every walk can use it, ties and flat boxes resolve as in
+ * the reference.  MIRT_BUILDER_DEVICE ignores desc->nodes / desc->leaf_prims (they may be NULL / 0, so the
+ * caller need not build a tree at all) and builds one on the GPU for large scenes: Morton codes of the
+ * primitives' box centres, radix sort, a binary radix tree, boxes fitted bottom-up (a moving primitive's
+ * box is the union of its boxes at matrix_t0 and matrix_t1, Sphere.cpp:85-99), emitted in the 4-wide
+ * form of the WIDE traversal -- the only traversal such a scene has.  The closest hit of a ray does not
+ * depend on the tree except where the reference's own rules make it: a box of zero thickness is never
+ * hit (BoundingBox.h:27), so a scene with planes is refused (MIRT_ERR_UNSUPPORTED), and hits at exactly
+ * equal distances may be won by the other surface (Bvh.cpp:312-332), as with WIDE on a host tree. */
+enum { MIRT_BUILDER_HOST = 0, MIRT_BUILDER_DEVICE = 1 };
+typedef struct mirt_build_options {
+  int32_t builder;    /* MIRT_BUILDER_* */
+  int32_t leaf_size;  /* DEVICE: most primitives of a leaf, 1 .. 4; 0: default (2 = MAX_LEAF_SIZE, Bvh.h:12) */
+  int32_t reserved[6];
+} mirt_build_options;
+/* mirt_scene_create with a choice of builder; options == NULL is mirt_scene_create. */
+int mirt_scene_create_with(const mirt_scene_desc *desc, int device, const mirt_build_options *options,
+                           mirt_scene **out);
+
+/* What a scene handle holds and what creating it cost (no counterpart in the reference, which logs its
+ * BVH build time and node counts, Raytracer.cpp:38-56). */
+typedef struct mirt_scene_info {
+  int32_t builder;         /* MIRT_BUILDER_* */
+  int32_t traversal;       /* MIRT_TRAVERSAL_* in use (never AUTO) */
+  int32_t n_prims;
+  int32_t n_wide_nodes;    /* 4-wide nodes and leaves of the WIDE traversal's tree */
+  int32_t n_leaves;
+  int32_t wide_depth;      /* its levels below the root */
+  int32_t bvh_depth;       /* HOST: depth of desc->nodes */
+  int32_t shadow_any_hit;  /* every primitive is opaque or perfectly clear: shadow rays stop at the first opaque hit */
+  double create_ms;        /* wall clock of mirt_scene_create*, uploads included */
+  double tree_ms;          /* of its BVH part (HOST: skip links, 4-wide collapse, upload; DEVICE: the build) */
+  double refit_ms;         /* of the last mirt_scene_refit */
+} mirt_scene_info;
+int mirt_scene_get_info(const mirt_scene *scene, mirt_scene_info *info);
+
+/* Moving the primitives of a scene whose tree was built on the device (animation: the next frame's
+ * transforms).  mirt_scene_update_prims replaces the records of primitives first .. first + count - 1
+ * (kind, material and has_motion must stay as they are); mirt_scene_refit then fits the existing tree
+ * to the new boxes, leaves up, without sorting or re-linking anything -- the tree stays correct for any
+ * placement and gets slower the further primitives stray from where they were built.  The reference
+ * rebuilds its tree for every frame it renders (Raytracer.cpp:26-46).  No frame may be in flight. */
+int mirt_scene_update_prims(mirt_scene *scene, int first, int count, const mirt_prim *prims);
+int mirt_scene_refit(mirt_scene *scene);
+
 /* Renders one frame; stands for `Raytracer::render` (Raytracer.cpp:475-607).
  * rgb_out: caller-owned HOST buffer of height * width * 3 doubles, row-major, the post-gamma,
  * un-clamped values the reference stores in Image.pixels (Raytracer.cpp:544-570).
@@ -299,7 +345,8 @@ int mirt_scene_progress(mirt_scene *scene, double *band_ms, int max_bands);
  * returns the same closest hit except that two surfaces at exactly the same distance may swap.
  * WIDE walks the same tree collapsed into 4-wide nodes, nearer child first like ORDERED, and runs the primitive
  * tests a kind at a time across the wave: the walk for large scenes (same closest hit, exact ties may swap).
- * AUTO: PACKET up to a few hundred primitives, LANE above. */
+ * AUTO: PACKET up to 512 primitives, WIDE above -- so by default a large scene trades the reference's order
+ * among hits at exactly equal distances for speed; LANE (or MIRT_TRAVERSAL=lane in the environment) restores it. */
 enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE = 2, MIRT_TRAVERSAL_ORDERED = 3,
        MIRT_TRAVERSAL_WIDE = 4 };
 int mirt_scene_set_traversal(mirt_scene *scene, int mode);

@@ -87,7 +87,24 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class BuildOptions(C.Structure):
+    _fields_ = [("builder", C.c_int32), ("leaf_size", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("builder", C.c_int32), ("traversal", C.c_int32), ("n_prims", C.c_int32),
+                ("n_wide_nodes", C.c_int32), ("n_leaves", C.c_int32), ("wide_depth", C.c_int32),
+                ("bvh_depth", C.c_int32), ("shadow_any_hit", C.c_int32), ("create_ms", C.c_double),
+                ("tree_ms", C.c_double), ("refit_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+MIRT_BUILDER_HOST, MIRT_BUILDER_DEVICE = 0, 1
+
 ENGINE_SYMBOLS = [
+    "mirt_scene_create_with", "mirt_scene_get_info", "mirt_scene_update_prims", "mirt_scene_refit",
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
     "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal", "mirt_render_tiles_begin", "mirt_render_tiles_end",
     "mirt_last_error", "mirt_abi_version", "mirt_render_tiles_noalloc", "mirt_noalloc_scratch_bytes",
@@ -102,6 +119,10 @@ def _declare_engine(lib):
     lib.mirt_config_defaults.argtypes = [C.POINTER(Config)]
     lib.mirt_config_defaults.restype = None
     lib.mirt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+    lib.mirt_scene_create_with.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(BuildOptions), C.POINTER(C.c_void_p)]
+    lib.mirt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+    lib.mirt_scene_update_prims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Prim)]
+    lib.mirt_scene_refit.argtypes = [C.c_void_p]
     lib.mirt_scene_destroy.argtypes = [C.c_void_p]
     lib.mirt_scene_destroy.restype = None
     lib.mirt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Config), C.c_int, C.c_int, C.c_int,
@@ -137,6 +158,10 @@ def _declare_engine(lib):
 def _declare_host(lib):
     lib.mirt_host_scene_synthetic.restype = C.c_void_p
     lib.mirt_host_scene_synthetic.argtypes = [C.c_int, C.c_uint64]
+    lib.mirt_host_scene_synthetic_opt.restype = C.c_void_p
+    lib.mirt_host_scene_synthetic_opt.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+    lib.mirt_host_scene_load_opt.restype = C.c_void_p
+    lib.mirt_host_scene_load_opt.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     lib.mirt_host_scene_write_ascii.restype = C.c_int
     lib.mirt_host_scene_write_ascii.argtypes = [C.c_void_p, C.c_char_p]
     lib.mirt_host_scene_load.restype = C.c_void_p

@@ -36,13 +36,13 @@ def default_config(**overrides):
 class HostScene:
     """A parsed + flattened scene (load_scene + BVH build + texture preload, all on the host)."""
 
-    def __init__(self, path, texture_root=None):
+    def __init__(self, path, texture_root=None, build_tree=True):
         lib = A.host_lib()
         if texture_root is None:
             # scenes live in <root>/ASCII/, textures in <root>/Textures/ (the reference's layout)
             texture_root = os.path.dirname(os.path.dirname(os.path.abspath(path)))
         self._lib = lib
-        self._h = lib.mirt_host_scene_load(os.fsencode(path), os.fsencode(texture_root))
+        self._h = lib.mirt_host_scene_load_opt(os.fsencode(path), os.fsencode(texture_root), 1 if build_tree else 0)
         if not self._h:
             raise MirtError(f"mirt_host_scene_load({path}): {lib.mirt_host_last_error().decode()}")
         self.path = path
@@ -50,12 +50,16 @@ class HostScene:
         lib.mirt_host_scene_desc(self._h, C.byref(self.desc))
 
     @classmethod
-    def synthetic(cls, n_prims, seed=0x5EED):
+    def synthetic(cls, n_prims, seed=0x5EED, build_tree=True):
         """The synthetic cloud of `n_prims` small spheres, tori, cylinders and cones
-        (raytracer_amd/host/synthetic.h), flattened like a parsed scene."""
+        (raytracer_amd/host/synthetic.h), flattened like a parsed scene.  build_tree=False skips the
+        host BVH build (for DeviceScene(..., builder="device")); flatten_ms is the wall clock of the
+        flattening, tree included when it was built."""
         self = cls.__new__(cls)
         self._lib = A.host_lib()
-        self._h = self._lib.mirt_host_scene_synthetic(int(n_prims), int(seed))
+        ms = C.c_double()
+        self._h = self._lib.mirt_host_scene_synthetic_opt(int(n_prims), int(seed), 1 if build_tree else 0, C.byref(ms))
+        self.flatten_ms = ms.value
         if not self._h:
             raise MirtError(f"mirt_host_scene_synthetic: {self._lib.mirt_host_last_error().decode()}")
         self.path = f"synthetic:{n_prims}:{seed}"
@@ -112,17 +116,38 @@ class HostScene:
 class DeviceScene:
     """A scene resident on one GPU (mirt_scene_create)."""
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, builder="host", leaf_size=0):
+        """builder: "host" (the tree in the description, the reference's) or "device" (built on the GPU,
+        plane-free scenes, wide walk only; the description needs no tree)."""
         self._lib = A.engine_lib()
         self._h = C.c_void_p()
         desc = scene.desc if isinstance(scene, HostScene) else scene
         self._keep = scene  # the description's arrays must outlive the call only, but keep it simple
-        _check(self._lib.mirt_scene_create(C.byref(desc), device, C.byref(self._h)), "mirt_scene_create")
+        opts = A.BuildOptions()
+        opts.builder = {"host": A.MIRT_BUILDER_HOST, "device": A.MIRT_BUILDER_DEVICE}[builder]
+        opts.leaf_size = leaf_size
+        _check(self._lib.mirt_scene_create_with(C.byref(desc), device, C.byref(opts), C.byref(self._h)),
+               "mirt_scene_create_with")
         self.device = device
 
+    def info(self):
+        """mirt_scene_get_info as a dict (builder, traversal in use, tree sizes, creation times)."""
+        i = A.SceneInfo()
+        _check(self._lib.mirt_scene_get_info(self._h, C.byref(i)), "mirt_scene_get_info")
+        return i.as_dict()
+
+    def update_prims(self, first, prims):
+        """New records (a ctypes array of mirt_prim) for primitives first .. of a device-built scene."""
+        _check(self._lib.mirt_scene_update_prims(self._h, first, len(prims), prims), "mirt_scene_update_prims")
+
+    def refit(self):
+        _check(self._lib.mirt_scene_refit(self._h), "mirt_scene_refit")
+
     def set_traversal(self, mode):
-        """mode: "auto", "packet" (wave-coherent BVH walk), "lane" (one walk per ray, the reference's
-        order) or "ordered" (one walk per ray, nearer child first)."""
+        """mode: "auto" (packet up to 512 primitives, wide above), "packet" (wave-coherent BVH walk),
+        "lane" (one walk per ray, the reference's order), "ordered" (one walk per ray, nearer child
+        first) or "wide" (4-wide nodes, nearer child first, primitive tests batched by kind).  Only
+        packet and lane resolve hits at exactly equal distances in the reference's order."""
         code = {"auto": 0, "packet": 1, "lane": 2, "ordered": 3, "wide": 4}[mode]
         _check(self._lib.mirt_scene_set_traversal(self._h, code), "mirt_scene_set_traversal")
 

@@ -31,9 +31,12 @@ static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte record");
 
 // BVH walks (see pipeline.h)
 enum : int32_t { WALK_PACKET = 0, WALK_LANE = 1, WALK_ORDERED = 2, WALK_WIDE = 3 };
-// leaf_tagged: leaf_prims with the primitive's kind in the top bits, for the walk that batches by kind
+// leaf_tagged: leaf_prims with the primitive's kind in the top bits, for the walk that batches by kind,
+// and one bit that says "transparency exactly 1": a shadow segment passes such a surface unattenuated
+// (Raytracer.cpp:190-198), so the any-hit form of the shadow walk does not test it at all
 #define LEAF_KIND_SHIFT 28
-#define LEAF_PRIM_MASK 0x0fffffff
+#define LEAF_CLEAR_BIT 0x08000000
+#define LEAF_PRIM_MASK 0x07ffffff
 
 // The wide walk's view of the same tree: the binary nodes collapsed two levels at a time.
 //   DWide  128 B  four slots: the grandchildren of a binary inner node (a child that is a leaf fills
@@ -60,7 +63,8 @@ struct alignas(64) DLeaf {
 static_assert(sizeof(DLeaf) == 64, "DLeaf must be 64 bytes");
 #define WIDE_NONE INT32_MIN
 #define LEAF_INDIRECT (INT32_MIN + 1)
-#define WIDE_STACK_DEEP 36  // per-lane stack entries beyond those in LDS (three per wide level at most)
+#define WIDE_STACK_LDS 12   // the wide walk's stack entries per lane kept in LDS; deeper ones go to the lane's private memory
+#define WIDE_STACK_DEEP 60  // per-lane stack entries beyond those in LDS (a visit pops one entry and pushes at most four)
 #define WALK_STACK 24  // entries of the ordered walk's per-lane stack: the tree may be this deep at most
 
 struct alignas(64) DPrim {
@@ -119,6 +123,11 @@ struct DScene {
   int32_t any_motion;    // some primitive has motion data
   int32_t any_maps;      // some material samples a texture, normal map or bump map
   int32_t max_children;  // most rays one hit can spawn, given the materials (and glossy_samples, added per frame)
+  // every primitive is either opaque (transparency <= 0) or perfectly clear (== 1): a shadow stratum is
+  // then 1 if any opaque primitive lies between the point and the light and 0 otherwise, and the shadow
+  // walk may stop at the first opaque hit it finds instead of chaining closest hits
+  int32_t shadow_any_hit;
+  int32_t pad_;
 };
 
 // Camera with the basis of Camera::get_ray (Camera.cpp:32-58) evaluated once on the host.
@@ -215,6 +224,8 @@ struct TraceArgs {
   DShadowItem *shadow;
   uint32_t *shadow_count;
   uint32_t shadow_shard_cap;
+  uint32_t shadow_groups;    // > 1: shadow items are queued by light, light li to shards [li * shadow_per, (li + 1) * shadow_per)
+  uint32_t shadow_per;
   int32_t depth;             // depth of the rays this launch traces
   double *accum;             // this rank's tile buffer: a red, a green and a blue plane of fr.plane doubles
   DCounters *counters;       // COUNTER_SHARDS replicas
@@ -278,13 +289,52 @@ void launch_deinterleave(unsigned grid, void *stream, const DeinterleaveArgs &a)
 // motion: some ray of the launch may be at a shutter time other than 0.5.
 void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
 void launch_shadow(int walk, bool strata, unsigned grid, void *stream, const ShadowArgs &a);  // strata: some light has more than one
-void launch_shadow_stream(unsigned grid, void *stream, const ShadowArgs &a);  // wide walk, resident grid
+// wide walk, resident grid; any_hit: segments end at the first opaque hit (DScene::shadow_any_hit)
+void launch_shadow_stream(bool any_hit, unsigned grid, void *stream, const ShadowArgs &a);
 // wide walk, two launches: closest hits by a resident grid, then shading with one lane per ray
 void launch_closest_stream(bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
 void launch_shade(bool primary, bool uv, unsigned grid, void *stream, const TraceArgs &a);
 void launch_resolve(unsigned grid, void *stream, const ResolveArgs &a);
 void launch_trace_ids(int walk, unsigned grid, void *stream, const IdsArgs &a);
 void launch_trace_rays(int walk, unsigned grid, void *stream, const RaysArgs &a);
+
+// ---- device-side BVH construction (bvh_build.h) ---------------------------------------------------
+// A binary radix tree over the primitives sorted by the Morton code of their box centres (internal
+// node i < n - 1, leaf k = sorted position k; a node reference is >= 0 for an internal node and ~k for
+// a leaf), its boxes fitted bottom-up, emitted top-down as the DWide / DLeaf arrays the wide walk reads.
+#define BUILD_REF_NONE INT32_MIN
+#define BUILD_SORT_ITEMS 16  // keys per lane of a sorting wave (one wave per block)
+#define BUILD_SORT_TILE (64 * BUILD_SORT_ITEMS)
+struct BuildArgs {
+  const DPrim *prims;
+  const double *motion_ends;   // per moving primitive (DPrim::motion_index): object_to_world rows 0-2 of matrix_t0, then of matrix_t1
+  const double *transparency;  // per primitive
+  uint32_t n, leaf_max;        // primitives; most primitives of a leaf (1 .. 4)
+  double *pbox;                // 6 per primitive: world box (min, max)
+  unsigned long long *bounds;  // 6 words: min x, y, z and max x, y, z of the box centres, in an order-preserving encoding
+  uint64_t *keys, *keys_alt;   // Morton codes; the sort ping-pongs between the two
+  uint32_t *ids, *ids_alt;     // the primitive at each sorted position
+  uint32_t *hist;              // 256 digit counts per sorting block, digit-major
+  uint32_t sort_blocks, shift;
+  int32_t *child;              // 2 per internal node
+  int32_t *parent;             // of the n - 1 internal nodes, then of the n leaves
+  uint32_t *range;             // 2 per internal node: first and last sorted position it covers
+  double *nbox;                // 6 per internal node
+  uint32_t *visits;            // per internal node: children fitted so far
+  DWide *wide;
+  DLeaf *leaves;
+  int32_t *wide_src;           // per wide node: the binary node it was collapsed from
+  int32_t *leaf_src;           // per DLeaf: the binary node (or leaf) it stands for
+  uint32_t *counters;          // [0] wide nodes allocated, [1] DLeafs allocated
+  uint32_t level_begin, level_end;  // k_build_emit: the wide nodes of this level
+};
+void launch_build_boxes(void *stream, const BuildArgs &a);
+void launch_build_keys(void *stream, const BuildArgs &a);
+void launch_build_sort_pass(void *stream, const BuildArgs &a);  // one 8-bit digit at a.shift: keys/ids -> keys_alt/ids_alt
+void launch_build_tree(void *stream, const BuildArgs &a);
+void launch_build_fit(void *stream, const BuildArgs &a);
+void launch_build_emit(void *stream, const BuildArgs &a);
+void launch_build_refresh(void *stream, const BuildArgs &a, uint32_t n_wide, uint32_t n_leaves);  // refit: boxes and order codes again
 
 // Size of the per-GPU static array behind mirt_render_tiles_noalloc (kernels.hip), and the device
 // address of the current device's copy of it (0, or a hipError_t).

@@ -5,17 +5,20 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../host/mirt_math.h"
+#include "bvh_device.h"
 #include "device_types.h"
 #include "mirt.h"
 #include "mirt_rng.h"
@@ -134,9 +137,20 @@ struct mirt_scene {
   hipEvent_t null_stream_mark = nullptr;  // orders the engine's own stream after the caller's null stream
   DScene d{};
   int wide_depth = 0;  // levels of the wide walk's tree below its root
+  uint32_t n_wide = 0, n_leaves = 0;  // of the tree collapsed on the host
   unsigned resident_grid = 768;  // blocks of a launch whose waves stay and take work off a queue: 3 per CU
   bool stream_kernels = true;
   DeviceBuffer nodes, leaf_prims, leaf_tagged, wide, leaves, prims, motion, materials, transparency, lights, textures, light_frame;
+  // MIRT_BUILDER_DEVICE: the tree was built on the GPU (the wide walk's arrays belong to `dbvh`), and what
+  // mirt_scene_update_prims / mirt_scene_refit need to move its primitives afterwards
+  int builder = MIRT_BUILDER_HOST;
+  std::unique_ptr<DeviceBvh> dbvh;
+  DeviceBuffer motion_ends;                 // 24 doubles per moving primitive: rows 0-2 of matrix_t0 and of matrix_t1
+  std::vector<double> motion_ends_host;
+  std::vector<DMotion> motion_host;
+  std::vector<int32_t> prim_material, prim_motion_index;  // per primitive; motion index -1: static
+  std::vector<uint8_t> prim_type;
+  double create_ms = 0.0, tree_ms = 0.0;    // wall clock of mirt_scene_create, and of its BVH part
   std::vector<DeviceBuffer> texels;
   std::vector<mirt_light> host_lights;
   SpawnKinds kinds;
@@ -211,16 +225,16 @@ void store_3x4(double *dst, const Mat4 &m) {
     for (int c = 0; c < 4; ++c) dst[r * 4 + c] = m.m[r][c];
 }
 
-int validate(const mirt_scene_desc *s) {
+int validate(const mirt_scene_desc *s, bool device_tree) {
   if (!s) return fail(MIRT_ERR_INVALID, "scene description is NULL");
-  if (s->n_nodes < 1 || !s->nodes) return fail(MIRT_ERR_INVALID, "scene needs at least one BVH node");
+  if (!device_tree && (s->n_nodes < 1 || !s->nodes)) return fail(MIRT_ERR_INVALID, "scene needs at least one BVH node");
   if (s->n_prims < 0 || s->n_leaf_prims < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_textures < 0 ||
       s->n_plane_points < 0)
     return fail(MIRT_ERR_INVALID, "negative count in scene description");
-  if ((s->n_prims && !s->prims) || (s->n_leaf_prims && !s->leaf_prims) || (s->n_materials && !s->materials) ||
+  if ((s->n_prims && !s->prims) || (!device_tree && s->n_leaf_prims && !s->leaf_prims) || (s->n_materials && !s->materials) ||
       (s->n_lights && !s->lights) || (s->n_textures && !s->textures) || (s->n_plane_points && !s->plane_points))
     return fail(MIRT_ERR_INVALID, "NULL array with a non-zero count");
-  for (int i = 0; i < s->n_nodes; ++i) {
+  for (int i = 0; i < s->n_nodes && !device_tree; ++i) {  // (a tree built on the device ignores the caller's)
     const mirt_node &n = s->nodes[i];
     if (n.left < 0) {
       if (n.count < 0 || n.first < 0 || (long long)n.first + n.count > s->n_leaf_prims)
@@ -231,7 +245,7 @@ int validate(const mirt_scene_desc *s) {
                   n.right);
     }
   }
-  for (int i = 0; i < s->n_leaf_prims; ++i)
+  for (int i = 0; i < s->n_leaf_prims && !device_tree; ++i)
     if (s->leaf_prims[i] < 0 || s->leaf_prims[i] >= s->n_prims)
       return fail(MIRT_ERR_INVALID, "leaf_prims[%d] = %d is not a primitive", i, s->leaf_prims[i]);
   for (int i = 0; i < s->n_prims; ++i) {
@@ -412,7 +426,7 @@ void prepare_plane(const mirt_scene_desc &s, const mirt_prim &p, DPrim &d) {
 
 // Decomposition half of Mat4::interpolate (Transform.cpp:239-247) and the t-independent part of
 // Quaternion::slerp (Quaternion.h:73-105).
-void prepare_motion(const mirt_prim &p, DPrim &d, std::vector<DMotion> &motion) {
+DMotion prepare_motion(const mirt_prim &p, DPrim &d) {
   const Mat4 a = mat_of(p.m0), b = mat_of(p.m1);
   DMotion mo;
   std::memset(&mo, 0, sizeof mo);
@@ -458,8 +472,36 @@ void prepare_motion(const mirt_prim &p, DPrim &d, std::vector<DMotion> &motion) 
   } else {
     d.motion = MOTION_GENERAL;
   }
-  d.motion_index = (int32_t)motion.size();
-  motion.push_back(mo);
+  return mo;
+}
+
+// The device record of primitive p: kind, flags, the static maps (a moving primitive: the maps at shutter
+// time 0.5, built the way the reference builds them per ray: interpolate, then invert, Sphere.cpp:9-11)
+// and the shape parameters.  A moving primitive's motion record goes to *mo and the first three rows of
+// its matrix_t0 / matrix_t1 to ends[0 .. 23] (its box is the union of the boxes at the two, Sphere.cpp:85-99);
+// its motion_index is left for the caller to set.
+void prepare_prim(const mirt_scene_desc &s, const mirt_prim &p, DPrim &d, DMotion *mo, double *ends) {
+  std::memset(&d, 0, sizeof d);
+  d.type = p.type;
+  d.visible = p.visible;
+  d.material = p.material;
+  d.motion = MOTION_NONE;
+  std::memcpy(d.param, p.param, sizeof d.param);
+  if (p.type == MIRT_PLANE) {  // no transform, no motion (Plane.cpp:8-92)
+    prepare_plane(s, p, d);
+    return;
+  }
+  if (p.has_motion) {
+    const Transform mid(Mat4::interpolate(mat_of(p.m0), mat_of(p.m1), 0.5));
+    store_3x4(d.xf, mid.world_to_object);
+    store_3x4(d.xf + 12, mid.object_to_world);
+    *mo = prepare_motion(p, d);
+    store_3x4(ends, mat_of(p.m0));
+    store_3x4(ends + 12, mat_of(p.m1));
+  } else {
+    store_3x4(d.xf, mat_of(p.w2o));
+    store_3x4(d.xf + 12, mat_of(p.o2w));
+  }
 }
 
 SpawnKinds spawn_kinds(const mirt_scene_desc &s) {
@@ -616,7 +658,15 @@ MIRT_API void mirt_scene_destroy(mirt_scene *scene) {
 MIRT_API int mirt_scene_set_traversal(mirt_scene *scene, int mode) {
   if (!scene) return fail(MIRT_ERR_INVALID, "NULL scene");
   const bool can_order = scene->bvh_depth < WALK_STACK;  // the ordered walk's per-lane stack
-  const bool can_wide = 3 * (scene->wide_depth + 1) <= WIDE_STACK_DEEP;  // the wide walk's (at most 3 pushes a level)
+  const bool can_wide = 3 * scene->wide_depth + 4 <= WIDE_STACK_LDS + WIDE_STACK_DEEP;  // the wide walk's: a visit pops one entry and pushes at most four
+  if (scene->builder == MIRT_BUILDER_DEVICE) {
+    // a tree built on the device exists as the wide walk's arrays only
+    if (mode != MIRT_TRAVERSAL_AUTO && mode != MIRT_TRAVERSAL_WIDE)
+      return fail(MIRT_ERR_UNSUPPORTED, "a scene whose BVH was built on the device has the wide walk only");
+    if (!can_wide) return fail(MIRT_ERR_UNSUPPORTED, "BVH deeper than the wide walk's stack");
+    scene->walk = WALK_WIDE;
+    return MIRT_OK;
+  }
   if (mode == MIRT_TRAVERSAL_AUTO) {
     // the packet walk visits the union of its 64 rays' paths: measured faster up to several hundred
     // primitives, slower from about a thousand; above that the wide walk (same closest hit, exact
@@ -647,16 +697,27 @@ MIRT_API int mirt_scene_set_traversal(mirt_scene *scene, int mode) {
 }
 
 namespace {
-int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out);
+int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_options &opts, mirt_scene **out);
 }
 
 // No exception leaves the library: the host-side tables of a scene are std::vectors, and a scene of
 // 10^6 primitives on a small host can run out of memory while they are filled.
-MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
+MIRT_API int mirt_scene_create_with(const mirt_scene_desc *desc, int device, const mirt_build_options *options,
+                                    mirt_scene **out) {
   if (!out) return fail(MIRT_ERR_INVALID, "out is NULL");
   *out = nullptr;
+  mirt_build_options opts;
+  std::memset(&opts, 0, sizeof opts);
+  if (options) opts = *options;
+  if (opts.builder != MIRT_BUILDER_HOST && opts.builder != MIRT_BUILDER_DEVICE)
+    return fail(MIRT_ERR_INVALID, "unknown BVH builder %d", opts.builder);
+  if (opts.leaf_size < 0 || opts.leaf_size > 4) return fail(MIRT_ERR_INVALID, "leaf_size must be 0 (default) or 1 .. 4");
   try {
-    return scene_create(desc, device, out);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = scene_create(desc, device, opts, out);
+    if (rc == MIRT_OK)
+      (*out)->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
   } catch (const std::bad_alloc &) {
     *out = nullptr;
     return fail(MIRT_ERR_MEMORY, "out of host memory while preparing the scene");
@@ -666,9 +727,21 @@ MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_sce
   }
 }
 
+MIRT_API int mirt_scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
+  return mirt_scene_create_with(desc, device, nullptr, out);
+}
+
 namespace {
-int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
-  if (int rc = validate(desc)) return rc;
+int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_options &opts, mirt_scene **out) {
+  const bool device_tree = opts.builder == MIRT_BUILDER_DEVICE;
+  if (int rc = validate(desc, device_tree)) return rc;
+  if (device_tree)
+    for (int i = 0; i < desc->n_prims; ++i)
+      if (desc->prims[i].type == MIRT_PLANE)
+        return fail(MIRT_ERR_UNSUPPORTED,
+                    "the device BVH builder takes no planes (primitive %d): a flat box is never hit "
+                    "(BoundingBox.h:27), so which planes are visible depends on the tree; build this scene's tree "
+                    "on the host", i);
   int n_dev = 0;
   HIP_TRY(hipGetDeviceCount(&n_dev));
   if (device < 0 || device >= n_dev) return fail(MIRT_ERR_DEVICE, "device %d not available (%d visible)", device, n_dev);
@@ -681,6 +754,7 @@ int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
     ~Guard() { delete s; }
   } guard{sc};
   sc->device = device;
+  sc->builder = opts.builder;
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&sc->null_stream_mark, hipEventDisableTiming));
   {
@@ -695,41 +769,33 @@ int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
   }
 
   const mirt_scene_desc &s = *desc;
-  std::vector<DNode> nodes(s.n_nodes);
-  int bvh_depth = 0;
-  if (fill_skip(s, nodes, 0, 0, bvh_depth) != s.n_nodes)
-    return fail(MIRT_ERR_INVALID, "BVH nodes are not one depth-first tree rooted at node 0");
-  sc->bvh_depth = bvh_depth;
+  if (s.n_prims > LEAF_PRIM_MASK) return fail(MIRT_ERR_UNSUPPORTED, "more than %d primitives", LEAF_PRIM_MASK);
 
   std::vector<DPrim> prims(s.n_prims);
-  std::vector<DMotion> motion;
+  std::vector<DMotion> &motion = sc->motion_host;
+  std::vector<double> &ends = sc->motion_ends_host;
   std::vector<double> transparency(s.n_prims);
-  bool any_maps = false;
+  sc->prim_type.resize(s.n_prims);
+  sc->prim_material.resize(s.n_prims);
+  sc->prim_motion_index.assign(s.n_prims, -1);
+  bool any_maps = false, any_hit = true;
   for (int i = 0; i < s.n_prims; ++i) {
     const mirt_prim &p = s.prims[i];
     DPrim &d = prims[i];
-    std::memset(&d, 0, sizeof d);
-    d.type = p.type;
-    d.visible = p.visible;
-    d.material = p.material;
-    d.motion = MOTION_NONE;
-    std::memcpy(d.param, p.param, sizeof d.param);
-    transparency[i] = s.materials[p.material].transparency;
-    if (p.type == MIRT_PLANE) {  // no transform, no motion (Plane.cpp:8-92)
-      prepare_plane(s, p, d);
-      continue;
+    DMotion mo;
+    double e[24];
+    prepare_prim(s, p, d, &mo, e);
+    if (d.motion != MOTION_NONE) {
+      d.motion_index = (int32_t)motion.size();
+      sc->prim_motion_index[i] = d.motion_index;
+      motion.push_back(mo);
+      ends.insert(ends.end(), e, e + 24);
     }
-    if (p.has_motion) {
-      // maps at shutter time 0.5 (all shadow rays, and all rays when motion blur is off), built
-      // the way the reference builds them per ray: interpolate, then invert (Sphere.cpp:9-11)
-      const Transform mid(Mat4::interpolate(mat_of(p.m0), mat_of(p.m1), 0.5));
-      store_3x4(d.xf, mid.world_to_object);
-      store_3x4(d.xf + 12, mid.object_to_world);
-      prepare_motion(p, d, motion);
-    } else {
-      store_3x4(d.xf, mat_of(p.w2o));
-      store_3x4(d.xf + 12, mat_of(p.o2w));
-    }
+    sc->prim_type[i] = (uint8_t)p.type;
+    sc->prim_material[i] = p.material;
+    const double tr = s.materials[p.material].transparency;
+    transparency[i] = tr;
+    if (tr > 0.0 && tr != 1.0) any_hit = false;  // attenuates: shadow segments must be chained through it
   }
   std::vector<mirt_material> materials(s.materials, s.materials + s.n_materials);
   for (const auto &m : materials)
@@ -752,15 +818,54 @@ int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
     textures[i].pad = 0;
   }
   sc->host_lights.assign(s.lights, s.lights + s.n_lights);
-  std::vector<int32_t> leaf(s.leaf_prims, s.leaf_prims + s.n_leaf_prims);
-  if (s.n_prims > LEAF_PRIM_MASK) return fail(MIRT_ERR_UNSUPPORTED, "more than %d primitives", LEAF_PRIM_MASK);
-  std::vector<int32_t> tagged(leaf);
-  for (auto &t : tagged) t |= s.prims[t].type << LEAF_KIND_SHIFT;
 
-  HIP_TRY(upload(sc->nodes, nodes));
-  HIP_TRY(upload(sc->leaf_prims, leaf));
-  HIP_TRY(upload(sc->leaf_tagged, tagged));
-  {
+  HIP_TRY(upload(sc->prims, prims));
+  HIP_TRY(upload(sc->motion, motion));
+  HIP_TRY(upload(sc->motion_ends, ends));
+  HIP_TRY(upload(sc->materials, materials));
+  HIP_TRY(upload(sc->transparency, transparency));
+  HIP_TRY(upload(sc->lights, sc->host_lights));
+  HIP_TRY(upload(sc->textures, textures));
+  HIP_TRY(sc->light_frame.reserve(std::max<size_t>(sizeof(DLightFrame) * s.n_lights, 16)));
+  sc->light_frame_host.resize(s.n_lights);
+
+  // ---- the tree ------------------------------------------------------------------------------------
+  const auto tree_t0 = std::chrono::steady_clock::now();
+  DScene &d = sc->d;
+  if (device_tree) {
+    // the reference-order walks have no tree here: one empty leaf stands in for their arrays
+    std::vector<DNode> nodes(1);
+    std::memset(nodes.data(), 0, sizeof(DNode));
+    nodes[0].skip = 1;
+    HIP_TRY(upload(sc->nodes, nodes));
+    HIP_TRY(upload(sc->leaf_prims, std::vector<int32_t>()));
+    HIP_TRY(upload(sc->leaf_tagged, std::vector<int32_t>()));
+    sc->bvh_depth = 0;
+    sc->dbvh.reset(new DeviceBvh);
+    const uint32_t leaf = opts.leaf_size ? (uint32_t)opts.leaf_size : (uint32_t)env_size("MIRT_DEVICE_LEAF", 2);
+    const int be = sc->dbvh->build(sc->stream, sc->prims.as<DPrim>(), sc->motion_ends.as<double>(),
+                                   sc->transparency.as<double>(), (uint32_t)s.n_prims, leaf);
+    if (be != 0)
+      return fail(be == (int)hipErrorOutOfMemory ? MIRT_ERR_MEMORY : MIRT_ERR_DEVICE, "device BVH build: %s",
+                  sc->dbvh->error.c_str());
+    sc->wide_depth = sc->dbvh->wide_depth;
+    d.wide = sc->dbvh->wide;
+    d.leaves = sc->dbvh->leaves;
+    d.n_nodes = 1;
+    if (int rc = mirt_scene_set_traversal(sc, MIRT_TRAVERSAL_AUTO)) return rc;
+  } else {
+    std::vector<DNode> nodes(s.n_nodes);
+    int bvh_depth = 0;
+    if (fill_skip(s, nodes, 0, 0, bvh_depth) != s.n_nodes)
+      return fail(MIRT_ERR_INVALID, "BVH nodes are not one depth-first tree rooted at node 0");
+    sc->bvh_depth = bvh_depth;
+    std::vector<int32_t> leaf(s.leaf_prims, s.leaf_prims + s.n_leaf_prims);
+    std::vector<int32_t> tagged(leaf);
+    for (auto &t : tagged)
+      t |= (s.prims[t].type << LEAF_KIND_SHIFT) | (transparency[t] == 1.0 ? LEAF_CLEAR_BIT : 0);
+    HIP_TRY(upload(sc->nodes, nodes));
+    HIP_TRY(upload(sc->leaf_prims, leaf));
+    HIP_TRY(upload(sc->leaf_tagged, tagged));
     WideBuilder wb{s, nodes, tagged, {}, {}};
     wb.wide.reserve(s.n_nodes / 3 + 1);
     wb.leaves.reserve(s.n_nodes / 2 + 1);
@@ -769,15 +874,13 @@ int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
     mirt_scene_set_traversal(sc, MIRT_TRAVERSAL_AUTO);  // needs n_prims, bvh_depth, wide_depth
     HIP_TRY(upload(sc->wide, wb.wide));
     HIP_TRY(upload(sc->leaves, wb.leaves));
+    d.wide = sc->wide.as<DWide>();
+    d.leaves = sc->leaves.as<DLeaf>();
+    d.n_nodes = s.n_nodes;
+    sc->n_wide = (uint32_t)wb.wide.size();
+    sc->n_leaves = (uint32_t)wb.leaves.size();
   }
-  HIP_TRY(upload(sc->prims, prims));
-  HIP_TRY(upload(sc->motion, motion));
-  HIP_TRY(upload(sc->materials, materials));
-  HIP_TRY(upload(sc->transparency, transparency));
-  HIP_TRY(upload(sc->lights, sc->host_lights));
-  HIP_TRY(upload(sc->textures, textures));
-  HIP_TRY(sc->light_frame.reserve(std::max<size_t>(sizeof(DLightFrame) * s.n_lights, 16)));
-  sc->light_frame_host.resize(s.n_lights);
+  sc->tree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tree_t0).count();
 
   // Everything mirt_render_tiles_noalloc will need, so that the call itself allocates nothing: the
   // address of this GPU's static array, the read-back buffer of the control block and the two
@@ -799,19 +902,15 @@ int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
     fw.fixed = true;
   }
 
-  DScene &d = sc->d;
   d.nodes = sc->nodes.as<DNode>();
   d.leaf_prims = sc->leaf_prims.as<int32_t>();
   d.leaf_tagged = sc->leaf_tagged.as<int32_t>();
-  d.wide = sc->wide.as<DWide>();
-  d.leaves = sc->leaves.as<DLeaf>();
   d.prims = sc->prims.as<DPrim>();
   d.motion = sc->motion.as<DMotion>();
   d.materials = sc->materials.as<mirt_material>();
   d.prim_transparency = sc->transparency.as<double>();
   d.lights = sc->lights.as<mirt_light>();
   d.textures = sc->textures.as<DTexture>();
-  d.n_nodes = s.n_nodes;
   d.n_prims = s.n_prims;
   d.n_lights = s.n_lights;
   d.n_textures = s.n_textures;
@@ -821,12 +920,92 @@ int scene_create(const mirt_scene_desc *desc, int device, mirt_scene **out) {
   d.any_motion = motion.empty() ? 0 : 1;
   d.any_maps = any_maps ? 1 : 0;
   d.max_children = 0;
+  {
+    const char *ah = std::getenv("MIRT_SHADOW_ANY_HIT");  // "0": chain closest hits even where any-hit is exact
+    d.shadow_any_hit = (any_hit && !(ah && ah[0] == '0')) ? 1 : 0;
+  }
 
   guard.s = nullptr;
   *out = sc;
   return MIRT_OK;
 }
 }  // namespace
+
+MIRT_API int mirt_scene_get_info(const mirt_scene *scene, mirt_scene_info *info) {
+  if (!scene || !info) return fail(MIRT_ERR_INVALID, "NULL argument");
+  std::memset(info, 0, sizeof *info);
+  info->builder = scene->builder;
+  info->traversal = scene->walk == WALK_PACKET ? MIRT_TRAVERSAL_PACKET
+                    : scene->walk == WALK_LANE ? MIRT_TRAVERSAL_LANE
+                    : scene->walk == WALK_ORDERED ? MIRT_TRAVERSAL_ORDERED
+                                                  : MIRT_TRAVERSAL_WIDE;
+  info->n_prims = scene->n_prims;
+  info->n_wide_nodes = (int32_t)(scene->dbvh ? scene->dbvh->n_wide : scene->n_wide);
+  info->n_leaves = (int32_t)(scene->dbvh ? scene->dbvh->n_leaves : scene->n_leaves);
+  info->wide_depth = scene->wide_depth;
+  info->bvh_depth = scene->bvh_depth;
+  info->shadow_any_hit = scene->d.shadow_any_hit;
+  info->create_ms = scene->create_ms;
+  info->tree_ms = scene->tree_ms;
+  info->refit_ms = scene->dbvh ? scene->dbvh->refit_ms : 0.0;
+  return MIRT_OK;
+}
+
+// New records for primitives [first, first + count) of a scene whose tree was built on the device.
+MIRT_API int mirt_scene_update_prims(mirt_scene *scene, int first, int count, const mirt_prim *prims) {
+  if (!scene || (!prims && count > 0)) return fail(MIRT_ERR_INVALID, "NULL argument");
+  if (scene->builder != MIRT_BUILDER_DEVICE)
+    return fail(MIRT_ERR_UNSUPPORTED, "only a scene whose BVH was built on the device can be refitted; flatten the "
+                "changed scene and create it again");
+  if (first < 0 || count < 0 || (long long)first + count > scene->n_prims)
+    return fail(MIRT_ERR_INVALID, "primitives [%d, %d) outside [0, %d)", first, first + count, scene->n_prims);
+  for (const auto &w : scene->work)
+    if (w.pending) return fail(MIRT_ERR_INVALID, "a frame is in flight: call mirt_render_tiles_end first");
+  if (count == 0) return MIRT_OK;
+  HIP_TRY(hipSetDevice(scene->device));
+  try {
+    std::vector<DPrim> recs((size_t)count);
+    bool moved = false;
+    mirt_scene_desc none;
+    std::memset(&none, 0, sizeof none);
+    for (int k = 0; k < count; ++k) {
+      const mirt_prim &p = prims[k];
+      const int i = first + k;
+      const int mi = scene->prim_motion_index[i];
+      if (p.type != scene->prim_type[i] || p.material != scene->prim_material[i] || (p.has_motion != 0) != (mi >= 0))
+        return fail(MIRT_ERR_INVALID, "primitive %d: kind, material and has_motion cannot change in an update", i);
+      DMotion mo;
+      double e[24];
+      prepare_prim(none, p, recs[k], &mo, e);
+      if (mi >= 0) {
+        recs[k].motion_index = mi;
+        scene->motion_host[mi] = mo;
+        std::memcpy(&scene->motion_ends_host[24 * (size_t)mi], e, sizeof e);
+        moved = true;
+      }
+    }
+    HIP_TRY(hipMemcpy(scene->prims.as<DPrim>() + first, recs.data(), recs.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+    if (moved) {
+      HIP_TRY(upload(scene->motion, scene->motion_host));
+      HIP_TRY(upload(scene->motion_ends, scene->motion_ends_host));
+    }
+  } catch (const std::bad_alloc &) {
+    return fail(MIRT_ERR_MEMORY, "out of host memory");
+  }
+  return MIRT_OK;
+}
+
+MIRT_API int mirt_scene_refit(mirt_scene *scene) {
+  if (!scene) return fail(MIRT_ERR_INVALID, "NULL scene");
+  if (scene->builder != MIRT_BUILDER_DEVICE || !scene->dbvh)
+    return fail(MIRT_ERR_UNSUPPORTED, "only a scene whose BVH was built on the device can be refitted");
+  for (const auto &w : scene->work)
+    if (w.pending) return fail(MIRT_ERR_INVALID, "a frame is in flight: call mirt_render_tiles_end first");
+  HIP_TRY(hipSetDevice(scene->device));
+  const int e = scene->dbvh->refit(scene->stream, scene->motion_ends.as<double>());
+  if (e != 0) return fail(MIRT_ERR_DEVICE, "device BVH refit: %s", scene->dbvh->error.c_str());
+  return MIRT_OK;
+}
 
 MIRT_API int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int tile_h, int rank, int world) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;
@@ -945,11 +1124,25 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   const size_t shard_blocks = (size_t)((grid_total + QUEUE_SHARDS - 1) / QUEUE_SHARDS);
   const size_t min_blocks = std::max<size_t>(1, (size_t)(spp + QUEUE_SHARDS - 1) / QUEUE_SHARDS);  // one pixel block, all samples
   const size_t accum_bytes = std::max<size_t>(n_pixels * 3 * sizeof(double), 64);
+  // Large scenes (wide walk): closest hits by a resident grid whose lanes take rays off a work counter,
+  // shading by a second launch; the hits of one launch wait in between.  Not with the static working
+  // memory, which has no room for them.
+  const bool streaming = sc->walk == WALK_WIDE && sc->stream_kernels && !ws->fixed;
+  // ... and their shadow items are queued by light (2 to 8 lights): light li owns `shadow_per` of the shards
+  uint32_t shadow_groups = 1, shadow_per = QUEUE_SHARDS;
+  if (streaming && n_lights >= 2 && n_lights <= 8 && env_size("MIRT_SHADOW_BY_LIGHT", 1) == 1) {
+    shadow_groups = (uint32_t)n_lights;
+    shadow_per = QUEUE_SHARDS / shadow_groups;
+  }
+  // most blocks of one launch that append to one shadow shard, and most items one block appends to it
+  const size_t shadow_blocks = shadow_groups > 1 ? (size_t)((grid_total + shadow_per - 1) / shadow_per) : shard_blocks;
+  const size_t shadow_min_blocks = shadow_groups > 1 ? std::max<size_t>(1, ((size_t)spp + shadow_per - 1) / shadow_per) : min_blocks;
+  const size_t block_items = shadow_groups > 1 ? 256 : 256 * (size_t)S;
   if (!ws->fixed) {
     size_t want_r = env_size("MIRT_RAY_QUEUE", (size_t)32 << 20) / QUEUE_SHARDS;
     size_t want_s = env_size("MIRT_SHADOW_QUEUE", (size_t)128 << 20) / QUEUE_SHARDS;
     want_r = std::max(std::min(want_r, shard_blocks * 256 * K), min_blocks * 256 * K);
-    want_s = std::max(std::min(want_s, shard_blocks * 256 * S * std::max(K, 1)), min_blocks * 256 * S);
+    want_s = std::max(std::min(want_s, shadow_blocks * block_items * std::max(K, 1)), shadow_min_blocks * block_items);
     if (want_r * QUEUE_SHARDS > 0xfffffff0u || want_s * QUEUE_SHARDS > 0xfffffff0u)
       return fail(MIRT_ERR_UNSUPPORTED, "queue too large");
     if (want_r > ws->ray_shard_cap) ws->ray_shard_cap = want_r;
@@ -1010,14 +1203,10 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   const bool motion = sc->d.any_motion && config->enable_motion_blur && config->sampling == MIRT_SAMPLING_JITTER;
 
   // pixel blocks per primary launch
-  const uint64_t fit =
-      (uint64_t)QUEUE_SHARDS * std::min(ws->shadow_shard_cap / (256 * (size_t)S), ws->ray_shard_cap / (size_t)256);
+  const uint64_t fit = std::min<uint64_t>((uint64_t)(shadow_groups > 1 ? shadow_per : QUEUE_SHARDS) * (ws->shadow_shard_cap / block_items),
+                                         (uint64_t)QUEUE_SHARDS * (ws->ray_shard_cap / (size_t)256));
   const uint64_t per_launch = std::max<uint64_t>(1, fit / (uint64_t)spp / sc->split);
   const size_t chunks = total_blocks ? (size_t)((total_blocks + per_launch - 1) / per_launch) : 0;
-  // Large scenes (wide walk): closest hits by a resident grid whose lanes take rays off a work counter,
-  // shading by a second launch; the hits of one launch wait in between.  Not with the static working
-  // memory, which has no room for them.
-  const bool streaming = sc->walk == WALK_WIDE && sc->stream_kernels && !ws->fixed;
   if (streaming) {
     const size_t most = std::max<size_t>((size_t)std::min<uint64_t>(per_launch, total_blocks) * (size_t)spp * 256,
                                          levels > 1 ? ws->ray_shard_cap * QUEUE_SHARDS : 0);
@@ -1083,6 +1272,8 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       a.shadow = ws->shadow_items.as<DShadowItem>();
       a.shadow_count = tails(c, depth, 1);
       a.shadow_shard_cap = (uint32_t)ws->shadow_shard_cap;
+      a.shadow_groups = shadow_groups;
+      a.shadow_per = shadow_per;
       a.accum = ws->accum.as<double>();
       a.counters = counters;
       a.first = (uint32_t)b0;
@@ -1135,7 +1326,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       }
       if (streaming) {
         sa.grab = a.shadow_count + 1;  // a spare word of the launch's tail block, zeroed with it
-        launch_shadow_stream(sc->resident_grid, stream, sa);
+        launch_shadow_stream(sc->d.shadow_any_hit != 0, sc->resident_grid, stream, sa);
       } else {
         launch_shadow(sc->walk, sc->any_strata, consumer_grid, stream, sa);
       }

@@ -2,6 +2,7 @@
 // pipeline.h and wraps their launches in plain C++ functions for the host-side engine.
 #include <hip/hip_runtime.h>
 
+#include "bvh_build.h"
 #include "pipeline.h"
 
 template <bool PRIMARY, bool UV, bool MOTION, int WALK>
@@ -98,8 +99,9 @@ void launch_shade(bool primary, bool uv, unsigned grid, void *stream, const Trac
   else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(256), 0, st, a);
 }
 
-void launch_shadow_stream(unsigned grid, void *stream, const ShadowArgs &a) {
-  hipLaunchKernelGGL(k_shadow_stream, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+void launch_shadow_stream(bool any_hit, unsigned grid, void *stream, const ShadowArgs &a) {
+  if (any_hit) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(k_shadow_stream<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
 }
 
 void launch_deinterleave(unsigned grid, void *stream, const DeinterleaveArgs &a) {

@@ -377,9 +377,6 @@ DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double
 #ifndef WIDE_DRAIN_MIN
 #define WIDE_DRAIN_MIN 24  // test a batch as soon as this many lanes hold a primitive of one kind
 #endif
-#ifndef WIDE_STACK_LDS
-#define WIDE_STACK_LDS 12  // stack entries per lane kept in LDS; deeper ones go to the lane's private memory
-#endif
 
 // A lane's place in the wide walk.  The walk is written as one wave step at a time (wide_step) so that
 // a kernel can interleave steps with handing finished lanes their next ray.
@@ -397,14 +394,23 @@ struct WideWalk {
     up = (ray.d.x >= 0.0 ? 1u : 0u) | (ray.d.y >= 0.0 ? 2u : 0u) | (ray.d.z >= 0.0 ? 4u : 0u);
   }
   DEV bool busy() const { return cur != WIDE_NONE || used != 0; }
+  DEV void stop() {  // drops what is left of the walk
+    sp = 0;
+    cur = WIDE_NONE;
+    used = 0;
+    km = 0;
+  }
 };
 
 // One step of the wave: the lanes that can walk visit their node or leaf, or -- when too few can --
 // the lanes holding a primitive of the most popular kind test it.  Returns false when no lane has
 // anything left.  Must be called by all lanes of the wave.
-template <bool SHADOW, bool UV, bool MOTION>
+// ANYHIT (shadow segments of a scene whose primitives are all opaque or perfectly clear): the question is
+// only whether an opaque primitive lies nearer than `any_limit`, so clear primitives are not tested at all
+// and a lane is done with its ray at the first hit nearer than the limit, whichever primitive it is on.
+template <bool SHADOW, bool UV, bool MOTION, bool ANYHIT = false>
 DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &closest_t, Best<UV> &best, WideWalk &w,
-                   int32_t *deep, unsigned &n_node, unsigned &n_prim) {
+                   int32_t *deep, unsigned &n_node, unsigned &n_prim, double any_limit = 0.0) {
   __shared__ int32_t stack_lds[WIDE_STACK_LDS][256];
   __shared__ int32_t pend[PEND_SLOTS][256];
   const int tid = threadIdx.x;
@@ -480,7 +486,7 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const int tag = lprim(k);
-              if (tag >= 0) {
+              if (tag >= 0 && !(ANYHIT && (tag & LEAF_CLEAR_BIT))) {
                 const int slot = __ffs(~w.used) - 1;
                 pend[slot][tid] = tag & LEAF_PRIM_MASK;
                 w.used |= 1u << slot;
@@ -493,7 +499,7 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
             const int n = indirect ? lp.y : 4;
             for (int k = 0; k < n; k++) {
               const int tag = indirect ? rdonly(sc.leaf_tagged)[lp.x + k] : lprim(k);
-              if (tag >= 0) {
+              if (tag >= 0 && !(ANYHIT && (tag & LEAF_CLEAR_BIT))) {
                 const int pi = tag & LEAF_PRIM_MASK;
                 n_prim++;
                 isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
@@ -503,6 +509,7 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
         }
       }
       w.cur = w.sp > 0 ? pop() : WIDE_NONE;
+      if (ANYHIT && best.prim >= 0 && best.t < any_limit) w.stop();
     }
     return true;
   }
@@ -515,6 +522,7 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
     w.km &= ~((1ull << slot) << (8 * kind));
     n_prim++;
     isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+    if (ANYHIT && best.prim >= 0 && best.t < any_limit) w.stop();
   }
   return true;
 }
@@ -882,6 +890,25 @@ DEV void queued_ray(const TraceArgs &a, size_t j, RaySeed &r) {
   r.pixel = a.in.pixel[j];
 }
 
+// Unshadowed Blinn-Phong contribution of one light to the pixel (Raytracer.cpp:266-285): `to` from the
+// point to the light, sn the shading normal, rd the ray direction; wd / ws the weights with which the
+// diffuse and the specular term enter the pixel.  Colour terms only: one reciprocal per normalisation
+// instead of three divisions.
+template <class L>
+DEV d3 light_term(const L &light, const mirt_config &cfg, d3 to, d3 sn, d3 rd, d3 wd, d3 ws, d3 tint, d3 specular,
+                  double shininess) {
+  const double inv_d = rsqrt_shade(len2(to));
+  const d3 ldir = to * inv_d;
+  const double ndl = maxd(0.0, dot(sn, ldir));
+  const d3 lin = ld3(light.color) * (light.intensity * cfg.light_intensity_factor * (inv_d * inv_d));
+  d3 c = wd * (tint * ndl) * lin;
+  const d3 hv = ldir + (-rd);
+  const double h2 = len2(hv);  // zero only when the light is exactly behind the eye ray
+  const double ndh = h2 > 0.0 ? maxd(0.0, dot(sn, hv) * rsqrt_shade(h2)) : 0.0;
+  if (ndh > 0.0) c = c + ws * (specular * pow_shade(ndh, shininess)) * lin;
+  return c;
+}
+
 // What trace() does with the closest hit (Raytracer.cpp:305-472), for the lanes of the wave with
 // `active` set: background for a miss, local terms without visibility, one shadow work item per
 // contributing light, and the rays the hit spawns.  Must be called by all lanes of the wave; the
@@ -970,7 +997,43 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
   const uint32_t n_samples = (uint32_t)cfg.glossy_samples;
   const uint32_t total = n_mirror + n_lobe * n_samples + n_reflect + n_refract;
   uint32_t ray_base = 0;
-  {
+  if (a.shadow_groups > 1) {
+    // Items sorted by light as they are queued (large scenes): light li appends to its own group of
+    // a.shadow_per shards, so that the shadow launch -- which works through the queue shard after shard --
+    // hands a wave 64 items that look towards the same light from neighbouring hits: their walks touch the
+    // same nodes.  One count per light in a byte of `packed` (at most 8 lights, at most 64 items each);
+    // lane li reserves light li's room, all lights in one atomic instruction.
+    unsigned long long packed = 0;
+    for (int li = 0; li < sc.n_lights; li++) {
+      const bool push = hit && lit && dot(sn, ld3(rdonly(sc.lights)[li].location) - sf.p) > 0.0;
+      packed |= (unsigned long long)__popcll(__ballot(push)) << (8 * li);
+    }
+    const int lane = __lane_id();
+    const uint32_t sub = shard % a.shadow_per;
+    uint32_t my_base = 0;
+    if (lane < sc.n_lights) {
+      const uint32_t cnt = (uint32_t)(packed >> (8 * lane)) & 0xffu;
+      if (cnt) my_base = atomicAdd(a.shadow_count + ((uint32_t)lane * a.shadow_per + sub) * QUEUE_COUNT_STRIDE, cnt);
+    }
+    if (lane == 0 && total) ray_base = atomicAdd(a.out_count + shard * QUEUE_COUNT_STRIDE, total);
+    ray_base = __shfl(ray_base, 0);
+    if (packed) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int li = 0; li < sc.n_lights; li++) {
+        const uint32_t base = __shfl(my_base, li);
+        if (!((packed >> (8 * li)) & 0xffull)) continue;  // wave-uniform
+        const RO mirt_light &L = rdonly(sc.lights)[li];
+        const d3 to = ld3(L.location) - sf.p;
+        const bool push = hit && lit && dot(sn, to) > 0.0;
+        d3 c = mk(0, 0, 0);
+        if (push) c = light_term(L, cfg, to, sn, ray.d, wd, ws, tint, ld3(m.specular), m.shininess);
+        const uint32_t r = base + (uint32_t)__popcll(__ballot(push) & below);
+        if (push && r < a.shadow_shard_cap)  // a full shard drops the item; the host redoes the frame
+          shadow_store(a.shadow, (size_t)((uint32_t)li * a.shadow_per + sub) * a.shadow_shard_cap + r, sf.p, c, key, pixel,
+                       (uint32_t)li);
+      }
+    }
+  } else {
     uint32_t items = 0;
     for (int li = 0; li < sc.n_lights; li++) {
       const bool push = hit && lit && dot(sn, ld3(rdonly(sc.lights)[li].location) - sf.p) > 0.0;
@@ -990,18 +1053,7 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
         d3 c = mk(0, 0, 0);
         const d3 to = ld3(L.location) - sf.p;
         const bool push = hit && lit && dot(sn, to) > 0.0;
-        if (push) {
-          // colour terms only: one reciprocal per normalisation instead of three divisions
-          const double inv_d = rsqrt_shade(len2(to));
-          const d3 ldir = to * inv_d;
-          const double ndl = maxd(0.0, dot(sn, ldir));
-          const d3 lin = ld3(L.color) * (L.intensity * cfg.light_intensity_factor * (inv_d * inv_d));
-          c = wd * (tint * ndl) * lin;
-          const d3 hv = ldir + (-ray.d);
-          const double h2 = len2(hv);  // zero only when the light is exactly behind the eye ray
-          const double ndh = h2 > 0.0 ? maxd(0.0, dot(sn, hv) * rsqrt_shade(h2)) : 0.0;
-          if (ndh > 0.0) c = c + ws * (ld3(m.specular) * pow_shade(ndh, m.shininess)) * lin;
-        }
+        if (push) c = light_term(L, cfg, to, sn, ray.d, wd, ws, tint, ld3(m.specular), m.shininess);
         const unsigned long long mask = __ballot(push);
         const uint32_t r = base + (uint32_t)__popcll(mask & below);
         if (push && r < a.shadow_shard_cap)  // a full shard drops the item; the host redoes the frame
@@ -1662,6 +1714,14 @@ __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k
 // (one atomic per WORK_CHUNK items) and hands them to its idle lanes whenever at least REFILL_MIN
 // lanes are idle, between steps of the walk.  What a lane does with an item is shadow_block's state
 // machine unchanged: strata, segments through transparent objects, attenuation, one pixel add.
+//
+// ANYHIT: every primitive of the scene is opaque or perfectly clear (transparency exactly 1, which leaves
+// the attenuation of Raytracer.cpp:190-198 as it is).  A stratum is then shadowed if and only if some
+// opaque primitive lies between the point and the light, so its one segment may end at the first such hit
+// found, in any order, and clear primitives need no test.  (The reference starts a new segment an epsilon
+// behind every clear surface and so skips whatever lies within two epsilons behind it; an opaque primitive
+// thin enough to lie wholly inside such a gap is found here and not there.)
+template <bool ANYHIT>
 __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_shadow_stream(const ShadowArgs a) {
   __shared__ double park_p[3][256], park_c[3][256], park_w[4][256];  // park_w: total att cur dist
   __shared__ uint64_t park_key[256];
@@ -1679,7 +1739,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
   WorkDealer dealer;
   bool has_item = false;
   RayL ray = make_ray(mk(0, 0, 0), mk(0, 0, 1), 0.5);
-  double eps = 0.0, closest = 0.0;
+  double eps = 0.0, closest = 0.0, limit = 0.0;
   Best<false> best;
   best.rec = nullptr;
   best.prim = -1;
@@ -1693,6 +1753,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
   auto begin_segment = [&](d3 P, d3 dir, double cur, double dist) {
     ray = make_ray(P + dir * cur, dir, 0.5);
     closest = dist - cur;
+    limit = closest;
     best.prim = -1;
     best.t = 0;
     n_seg++;
@@ -1760,7 +1821,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_sh
       continue;  // nothing in hand but the queue is not empty: refill (the condition above holds now)
     }
     // ---- one step of the walk ----------------------------------------------------------------------
-    wide_step<true, false, false>(sc, ray, eps, closest, best, w, deep, n_node, n_prim);
+    wide_step<true, false, false, ANYHIT>(sc, ray, eps, closest, best, w, deep, n_node, n_prim, limit);
     // ---- lanes whose segment is over ---------------------------------------------------------------
     if (has_item && !w.busy()) {
       double att = park_w[1][tid], cur = park_w[2][tid];

@@ -1,6 +1,7 @@
 // C entry points of the host library (libmirt_host.so) for callers that are not C++ (the Python
 // tests and bench drive the loader and the flattening through these with ctypes).  They wrap
 // load_scene + flatten_scene and the PPM writer; none of them touches the GPU.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -102,6 +103,25 @@ void *mirt_host_scene_synthetic(int n_prims, uint64_t seed) {
   return make_scene([&](HostScene &h) {
     h.scene = make_synthetic_scene(n_prims, seed);
     h.flat = flatten_scene(h.scene, "");
+  });
+}
+
+// The same without the host BVH build (for MIRT_BUILDER_DEVICE); *flatten_ms gets the wall clock of the
+// flattening alone (build_tree != 0: tree included), the scene generation not counted.
+void *mirt_host_scene_synthetic_opt(int n_prims, uint64_t seed, int build_tree, double *flatten_ms) {
+  return make_scene([&](HostScene &h) {
+    h.scene = make_synthetic_scene(n_prims, seed);
+    const auto t0 = std::chrono::steady_clock::now();
+    h.flat = flatten_scene(h.scene, "", build_tree != 0);
+    if (flatten_ms) *flatten_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  });
+}
+
+// Parses `path` and flattens it without building the tree.
+void *mirt_host_scene_load_opt(const char *path, const char *texture_root, int build_tree) {
+  return make_scene([&](HostScene &h) {
+    h.scene = load_scene(path ? path : "");
+    h.flat = flatten_scene(h.scene, texture_root ? texture_root : "", build_tree != 0);
   });
 }
 

@@ -211,7 +211,7 @@ mirt_scene_desc FlatScene::desc() const {
   return d;
 }
 
-FlatScene flatten_scene(const Scene &scene, const std::string &texture_root) {
+FlatScene flatten_scene(const Scene &scene, const std::string &texture_root, bool build_tree) {
   FlatScene fs;
   std::string root = texture_root;
   if (!root.empty() && root.back() != '/') root.push_back('/');
@@ -288,10 +288,12 @@ FlatScene flatten_scene(const Scene &scene, const std::string &texture_root) {
     add(s, p, moving_or_static_box(s, BoundingBox{Point(-r, -r, -h), Point(r, r, h)}), s.location);
   }
 
-  b.order.resize(total);
-  for (std::size_t i = 0; i < total; ++i) b.order[i] = static_cast<int32_t>(i);
-  b.run();  // an empty scene still gets its one empty leaf
-  fs.leaf_prims = std::move(b.order);
+  if (build_tree) {
+    b.order.resize(total);
+    for (std::size_t i = 0; i < total; ++i) b.order[i] = static_cast<int32_t>(i);
+    b.run();  // an empty scene still gets its one empty leaf
+    fs.leaf_prims = std::move(b.order);
+  }
 
   for (const auto &l : scene.lights) {
     mirt_light o;

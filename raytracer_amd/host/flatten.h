@@ -29,7 +29,9 @@ struct FlatScene {
 
 // texture_root: directory that holds `Textures/`; empty = the current directory, as in the
 // reference (Code/IO/Texture.cpp:37-45).
-FlatScene flatten_scene(const Scene &scene, const std::string &texture_root = "");
+// build_tree = false leaves nodes and leaf_prims empty, for an engine scene whose tree is built on the
+// device (mirt_scene_create_with, MIRT_BUILDER_DEVICE).
+FlatScene flatten_scene(const Scene &scene, const std::string &texture_root = "", bool build_tree = true);
 
 mirt_camera flatten_camera(const Camera &camera);
 mirt_config flatten_config(const RenderConfig &config);

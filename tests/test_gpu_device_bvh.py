@@ -1,0 +1,341 @@
+"""The BVH built on the GPU (mirt_scene_create_with, MIRT_BUILDER_DEVICE) and its refit: the closest hit of
+a ray does not depend on the tree, so hits and frames must equal the oracle's -- which walks the host
+tree of the same scene, pinned to the reference -- to the same bounds as the host-built tree's."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import FIXTURES, GOLDEN, SYNTHETIC, scene_path
+from raytracer_amd import DeviceScene, HostScene, MirtError, default_config
+from raytracer_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 9, 64, 1000])
+@pytest.mark.parametrize("leaf", [1, 2, 4])
+def test_small_clouds(n, leaf):
+    """Degenerate sizes: no primitive, a tree that is one leaf, leaves of every size, odd counts."""
+    hs = HostScene.synthetic(n, seed=77)
+    dd = DeviceScene(hs, 0, builder="device", leaf_size=leaf)
+    info = dd.info()
+    assert info["builder"] == 1 and info["traversal"] == 4 and info["n_prims"] == n
+    assert info["n_wide_nodes"] >= 1 and (info["n_leaves"] >= (n + leaf - 1) // leaf if n else info["n_leaves"] == 0)
+    # rays aimed at the primitives from outside the cloud, so that most of them hit something
+    rng = np.random.default_rng(n + 1)
+    m = 4096
+    if n:
+        centres = np.array([[hs.desc.prims[i].o2w[3], hs.desc.prims[i].o2w[7], hs.desc.prims[i].o2w[11]] for i in range(n)])
+        target = centres[rng.integers(0, n, m)] + rng.normal(scale=0.05, size=(m, 3))
+    else:
+        target = rng.normal(size=(m, 3))
+    origin = rng.normal(size=(m, 3))
+    origin = 400.0 * origin / np.linalg.norm(origin, axis=1, keepdims=True)
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ref = O.trace_rays(hs.desc, origin, d, None)
+    got = dd.trace_rays(origin, d)
+    same = got["prim_id"] == ref["prim_id"]
+    print(f"n={n} leaf={leaf}: {info['n_wide_nodes']} wide nodes, {info['n_leaves']} leaves, depth {info['wide_depth']}, "
+          f"hits {(ref['prim_id'] >= 0).mean():.3f}, agreement {same.mean():.5f}")
+    assert same.mean() >= 0.999
+    hit = same & (ref["prim_id"] >= 0)
+    if n:
+        assert (ref["prim_id"] >= 0).mean() > 0.3
+        # same intersectors whatever the tree: everything but the torus to rounding; a torus a few hundredths
+        # across seen from 400 units away to what its quartic resolves (the oracle solves it in long double,
+        # the device re-centred in double: see test_closest_hit_vs_golden_and_oracle)
+        kinds = np.array([hs.desc.prims[i].type for i in range(n)])
+        torus = kinds[np.maximum(ref["prim_id"], 0)] == A.MIRT_TORUS
+        rel = np.abs(got["t"] - ref["t"]) / np.maximum(ref["t"], 1.0)
+        print(f"   distance: max relative error {rel[hit & ~torus].max(initial=0):.2e} (not tori), {rel[hit & torus].max(initial=0):.2e} (tori)")
+        assert rel[hit & ~torus].max(initial=0) <= 1e-9
+        # (from this far the reference's own torus roots are off by up to units: no bound against the oracle;
+        # against the engine's walk of the host tree the same primitive gives the same distance, bit for bit)
+        host = DeviceScene(hs, 0)
+        host.set_traversal("wide")
+        other = host.trace_rays(origin, d)
+        agree = other["prim_id"] == got["prim_id"]
+        assert agree.mean() >= 0.9995
+        assert np.array_equal(other["t"][agree], got["t"][agree])
+
+
+def test_planes_are_refused_and_other_walks_too(host_scenes):
+    hs = host_scenes("Test5")  # has a ground plane
+    with pytest.raises(MirtError, match="planes"):
+        DeviceScene(hs, 0, builder="device")
+    cloud = HostScene.synthetic(500)
+    dd = DeviceScene(cloud, 0, builder="device")
+    for walk in ("packet", "lane", "ordered"):
+        with pytest.raises(MirtError, match="wide walk only"):
+            dd.set_traversal(walk)
+    dd.set_traversal("wide")
+    dd.set_traversal("auto")
+    host = DeviceScene(cloud, 0)
+    with pytest.raises(MirtError, match="built on the device"):
+        host.refit()
+
+
+def test_scene_without_a_host_tree():
+    """The caller need not build a tree at all: a description with no nodes is accepted by the device
+    builder and refused by the host one."""
+    with_tree = HostScene.synthetic(3000, seed=5)
+    bare = HostScene.synthetic(3000, seed=5, build_tree=False)
+    assert bare.desc.n_nodes == 0 and bare.desc.n_leaf_prims == 0 and bare.desc.n_prims == 3000
+    with pytest.raises(MirtError):
+        DeviceScene(bare, 0)
+    dd = DeviceScene(bare, 0, builder="device")
+    cam, _ = bare.camera(0)
+    cfg = default_config(max_ray_depth=4)
+    got, st = dd.render(cam, cfg, 96, 54, 2)
+    want, ost = O.render(with_tree.desc, cam, cfg, 96, 54, 2, O.RNG_KEYED)
+    assert st["primary_rays"] == ost["primary_rays"]
+    assert O.psnr(got, want) >= 60.0
+
+
+def test_cloud_100k_vs_reference_golden(host_scenes):
+    """Closest hits on the 10^5-primitive cloud against the reference's own (tests/golden)."""
+    hs = host_scenes("synthetic100k")
+    dd = DeviceScene(hs, 0, builder="device")
+    cam, _ = hs.camera(0)
+    gold = np.load(os.path.join(GOLDEN, "hits_synthetic100k.npz"))
+    got = dd.trace_ids(cam, 96, 54)
+    same = got["prim_id"] == gold["prim_id"]
+    print(f"100k cloud, device tree: prim-id agreement with the reference {same.mean():.6f}; {dd.info()}")
+    assert same.mean() >= 0.999
+    cfg = default_config(max_ray_depth=5, enable_motion_blur=0, sampling=1, enable_gamma_correction=0)
+    frame, _ = dd.render(cam, cfg, 96, 54, 1)
+    p = O.psnr(frame, gold["trace_rgb_depth5"].reshape(54, 96, 3))
+    print(f"100k cloud, device tree: depth-5 colours vs the reference {p:.1f} dB")
+    assert p >= 60.0
+
+
+@pytest.fixture(scope="module")
+def million():
+    hs = HostScene.synthetic(1000000, 0x5EED)
+    return hs, DeviceScene(hs, 0, builder="device")
+
+
+def test_million_primitive_cloud_on_the_device_tree(million):
+    """The checks of the host-built tree (test_gpu_parity.py) on the device-built one: ids >= 99.9 %,
+    a stochastic frame >= 60 dB against the oracle."""
+    hs, dd = million
+    info = dd.info()
+    print(f"10^6 cloud, device tree: {info}")
+    assert info["shadow_any_hit"] == 1  # the cloud's glass is perfectly clear
+    cam, _ = hs.camera(0)
+    w, h = 192, 108
+    ref = O.trace_ids(hs.desc, cam, w, h)
+    got = dd.trace_ids(cam, w, h)
+    same = got["prim_id"] == ref["prim_id"]
+    hit = same & (ref["prim_id"] >= 0)
+    print(f"10^6 cloud, device tree: prim-id agreement {same.mean():.6f}")
+    assert same.mean() >= 0.999
+    assert np.allclose(got["t"][hit], ref["t"][hit], rtol=2e-5, atol=0)
+    cfg = default_config(max_ray_depth=5)
+    want, ost = O.render(hs.desc, cam, cfg, 96, 54, 2)
+    frame, st = dd.render(cam, cfg, 96, 54, 2)
+    p, mae = O.psnr(frame, want), float(np.abs(frame - want).mean())
+    off = np.abs(frame - want).max(axis=2) > 1e-6
+    print(f"10^6 cloud, device tree: PSNR {p:.1f} dB, MAE {mae:.3e}, {int(off.sum())} of {off.size} pixels differ")
+    assert st["primary_rays"] == ost["primary_rays"]
+    assert abs(st["secondary_rays"] - ost["secondary_rays"]) <= max(2, 2e-3 * ost["secondary_rays"])
+    assert p >= 60.0 and mae <= 2e-5 and off.mean() <= 1e-2  # far tori: see test_million_primitive_cloud_vs_oracle
+
+
+def test_million_primitive_cloud_at_4k_on_the_device_tree(million):
+    from test_gpu_parity import crop_vs_oracle
+    hs, dd = million
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=5)
+    crop_vs_oracle(dd, hs, cam, cfg, 3840, 2160, 16, [(1904, 1072, 32, 18), (1000, 600, 32, 18)], max_mae=5e-5)
+
+
+def moved_copy(hs, rng, frac=1.0, shift=0.5):
+    """A ctypes copy of the scene's primitive records with a share of them translated (static ones through
+    object_to_world / world_to_object, moving ones through matrix_t0 / matrix_t1) and rescaled."""
+    n = hs.desc.n_prims
+    prims = (A.Prim * n)()
+    C.memmove(prims, hs.desc.prims, C.sizeof(A.Prim) * n)
+    for i in range(n):
+        if rng.random() > frac:
+            continue
+        t = rng.normal(scale=shift, size=3)
+        p = prims[i]
+        for mat in (p.o2w, p.m0, p.m1):
+            for r in range(3):
+                mat[4 * r + 3] += t[r]
+        # world_to_object = (T(t) M)^-1 = M^-1 T(-t): its translation column changes by -M^-1 t
+        w = np.array(p.w2o[:]).reshape(4, 4)
+        w[:3, 3] -= w[:3, :3] @ t
+        for k in range(16):
+            p.w2o[k] = w.flat[k]
+    return prims
+
+
+def with_prims(desc, prims):
+    d = type(desc).from_buffer_copy(desc)
+    d.prims = C.cast(prims, C.POINTER(A.Prim))
+    return d
+
+
+def test_refit_follows_moved_primitives():
+    """Primitives move, the tree is refitted (no sort, no new topology), and the scene renders what a scene
+    built from scratch at the new positions renders."""
+    hs = HostScene.synthetic(20000, seed=9)
+    dd = DeviceScene(hs, 0, builder="device")
+    cam, _ = hs.camera(0)
+    rng = np.random.default_rng(3)
+    before = dd.trace_ids(cam, 192, 108)["prim_id"]
+    prims = moved_copy(hs, rng, frac=0.7, shift=3.0)
+    moved = with_prims(hs.desc, prims)
+    fresh = DeviceScene(moved, 0, builder="device")  # a new tree for the moved scene (the description's host tree is stale)
+    dd.update_prims(0, prims)
+    dd.refit()
+    assert dd.info()["refit_ms"] > 0.0
+    a, b = dd.trace_ids(cam, 192, 108), fresh.trace_ids(cam, 192, 108)
+    same = a["prim_id"] == b["prim_id"]
+    print(f"refit: {same.mean():.6f} of the pixels agree with a fresh build; {float((a['prim_id'] != before).mean()):.3f} changed owner")
+    assert (a["prim_id"] != before).mean() > 0.01  # the move is visible
+    assert same.mean() >= 0.9999
+    hit = same & (a["prim_id"] >= 0)
+    assert np.array_equal(a["t"][hit], b["t"][hit])
+    # rays from inside the cloud in all directions.  The closest hit does not depend on the tree -- except
+    # on tori a few hundredths across seen from a hundred units away, where the quartic's roots are noise
+    # (in the reference's long double too) and a ray that merely passes near one may be given a hit: whether
+    # such a torus is tested at all depends on whose leaf box the ray enters.  So: every disagreement
+    # involves a torus, and there are few.
+    m = 400000
+    o = rng.uniform(-110, 110, size=(m, 3))
+    d = rng.normal(size=(m, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ra, rb = dd.trace_rays(o, d), fresh.trace_rays(o, d)
+    kinds = np.array([hs.desc.prims[i].type for i in range(hs.desc.n_prims)] + [-1])
+    differ = ra["prim_id"] != rb["prim_id"]
+    torus = (kinds[ra["prim_id"]] == A.MIRT_TORUS) | (kinds[rb["prim_id"]] == A.MIRT_TORUS)
+    print(f"refit: {int(differ.sum())} of {m} interior rays differ from a fresh build, {int((differ & torus).sum())} of them on tori; "
+          f"{int((rb['prim_id'] >= 0).sum())} hits")
+    assert (differ & ~torus).sum() == 0
+    assert differ.sum() <= 1e-3 * (rb["prim_id"] >= 0).sum()
+    agree = ~differ & (ra["prim_id"] >= 0)
+    assert np.array_equal(ra["t"][agree], rb["t"][agree])
+    cfg = default_config(max_ray_depth=4)
+    fa, sa = dd.render(cam, cfg, 160, 90, 2)
+    fb, sb = fresh.render(cam, cfg, 160, 90, 2)
+    off = np.abs(fa - fb).max(axis=2) > 1e-9
+    print(f"refit: {int(off.sum())} of {off.size} pixels of a depth-4 frame differ from a fresh build's")
+    assert abs(sa["secondary_rays"] - sb["secondary_rays"]) <= 4 and off.mean() <= 1e-3
+    # brute force: rays against the moved primitives through the oracle with a one-leaf tree
+    nodes = (A.Node * 1)()
+    nodes[0].left = nodes[0].right = -1
+    nodes[0].first, nodes[0].count = 0, 300
+    for k in range(3):
+        nodes[0].bmin[k], nodes[0].bmax[k] = -1e9, 1e9
+    sub = type(hs.desc).from_buffer_copy(moved)
+    ids = (C.c_int32 * 300)(*range(300))
+    sub.nodes, sub.n_nodes = C.cast(nodes, C.POINTER(A.Node)), 1
+    sub.leaf_prims, sub.n_leaf_prims = C.cast(ids, C.POINTER(C.c_int32)), 300
+    centres = np.array([[prims[i].o2w[3], prims[i].o2w[7], prims[i].o2w[11]] for i in range(300)])
+    origin = rng.normal(size=(2000, 3))
+    origin = 500.0 * origin / np.linalg.norm(origin, axis=1, keepdims=True)
+    d = centres[rng.integers(0, 300, 2000)] - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ref = O.trace_rays(sub, origin, d, None)          # closest among the first 300 primitives only
+    got = dd.trace_rays(origin, d)                    # closest among all 20000
+    # whatever the full scene hits is at most as far as what the subset hits
+    both = (ref["prim_id"] >= 0)
+    assert (got["prim_id"][both] >= 0).all()
+    assert (got["t"][both] <= ref["t"][both] * (1 + 1e-9)).all()
+    assert (got["prim_id"][both] == ref["prim_id"][both]).mean() > 0.5
+    # bad updates are refused
+    bad = (A.Prim * 1)()
+    C.memmove(bad, hs.desc.prims, C.sizeof(A.Prim))
+    bad[0].type = (bad[0].type + 3) % 6
+    with pytest.raises(MirtError, match="cannot change"):
+        dd.update_prims(0, bad)
+    with pytest.raises(MirtError):
+        dd.update_prims(19999, prims)  # runs past the end
+
+
+def test_moving_primitives_get_the_union_of_their_end_boxes():
+    """A primitive with motion blur is boxed by box(matrix_t0) U box(matrix_t1) (Sphere.cpp:85-99), on the
+    device as on the host.  A cloud whose spheres fly along x by less than their own width (so that the
+    union of the two boxes is the box of the whole sweep and a tree loses no hit), against a brute-force
+    oracle at random shutter times: a builder that boxed only one end would miss hits at the other."""
+    hs = HostScene.synthetic(4000, seed=21)
+    n = hs.desc.n_prims
+    rng = np.random.default_rng(8)
+    moving = [i for i in range(n) if hs.desc.prims[i].type == A.MIRT_SPHERE]
+    for i in moving:
+        p = hs.desc.prims[i]
+        p.has_motion = 1
+        width = 2.0 * (abs(p.o2w[0]) + abs(p.o2w[1]) + abs(p.o2w[2]))  # x extent of the box of [-1, 1]^3
+        for k in range(16):
+            p.m0[k] = p.o2w[k]
+            p.m1[k] = p.o2w[k]
+        p.m1[3] += 0.9 * width * (1 if rng.random() < 0.5 else -1)
+    dd = DeviceScene(hs, 0, builder="device")
+    m = 3000
+    centres = np.array([[hs.desc.prims[i].o2w[3], hs.desc.prims[i].o2w[7], hs.desc.prims[i].o2w[11]] for i in range(n)])
+    origin = rng.normal(size=(m, 3))
+    origin = 400.0 * origin / np.linalg.norm(origin, axis=1, keepdims=True)
+    aim = np.where(rng.random(m) < 0.7, rng.choice(moving, m), rng.integers(0, n, m))
+    d = centres[aim] + rng.normal(scale=0.1, size=(m, 3)) - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tm = rng.random(m)
+    # brute force through the oracle: one leaf holding everything (the host tree in hs.desc was built for
+    # the boxes of the static scene)
+    nodes = (A.Node * 1)()
+    nodes[0].left = nodes[0].right = -1
+    nodes[0].first, nodes[0].count = 0, n
+    for k in range(3):
+        nodes[0].bmin[k], nodes[0].bmax[k] = -1e9, 1e9
+    ids = (C.c_int32 * n)(*range(n))
+    brute = type(hs.desc).from_buffer_copy(hs.desc)
+    brute.nodes, brute.n_nodes = C.cast(nodes, C.POINTER(A.Node)), 1
+    brute.leaf_prims, brute.n_leaf_prims = C.cast(ids, C.POINTER(C.c_int32)), n
+    ref = O.trace_rays(brute, origin, d, tm)
+    got = dd.trace_rays(origin, d, tm)
+    same = got["prim_id"] == ref["prim_id"]
+    is_moving = np.zeros(n + 1, bool)
+    is_moving[moving] = True
+    moving_hits = int(is_moving[ref["prim_id"]][ref["prim_id"] >= 0].sum())
+    late = (ref["prim_id"] >= 0) & is_moving[np.maximum(ref["prim_id"], 0)] & (tm > 0.8)
+    print(f"moving cloud: agreement {same.mean():.5f} over {m} rays, {moving_hits} hits on moving spheres, "
+          f"{int(late.sum())} of them late in the shutter")
+    assert moving_hits > 200 and late.sum() > 20
+    assert same.mean() >= 0.999
+    assert same[late].mean() >= 0.99
+    kinds = np.array([hs.desc.prims[i].type for i in range(n)] + [-1])
+    hit = same & (ref["prim_id"] >= 0) & (kinds[ref["prim_id"]] != A.MIRT_TORUS)  # (far tori: root noise on both sides)
+    assert np.allclose(got["t"][hit], ref["t"][hit], rtol=1e-9, atol=1e-12)
+
+
+def test_any_hit_shadows_equal_chained_shadows(monkeypatch):
+    """On a scene whose primitives are all opaque or perfectly clear the shadow walk stops at the first
+    opaque hit; MIRT_SHADOW_ANY_HIT=0 chains closest hits as the reference does.  Same frame, up to the
+    opaque slivers that lie within two epsilons behind a clear surface."""
+    hs = HostScene.synthetic(100000)
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=4)
+    fast = DeviceScene(hs, 0)
+    assert fast.info()["shadow_any_hit"] == 1
+    a, sa = fast.render(cam, cfg, 480, 270, 2)
+    monkeypatch.setenv("MIRT_SHADOW_ANY_HIT", "0")
+    slow = DeviceScene(hs, 0)
+    assert slow.info()["shadow_any_hit"] == 0
+    b, sb = slow.render(cam, cfg, 480, 270, 2)
+    differ = float((np.abs(a - b).max(axis=2) > 1e-9).mean())
+    print(f"any-hit vs chained: {differ:.2e} of the pixels differ; shadow box tests {sa['shadow_node_tests']} vs "
+          f"{sb['shadow_node_tests']}, primitive tests {sa['shadow_prim_tests']} vs {sb['shadow_prim_tests']}, "
+          f"segments {sa['shadow_segments']} vs {sb['shadow_segments']}")
+    assert sa["secondary_rays"] == sb["secondary_rays"]
+    assert sa["shadow_segments"] <= sb["shadow_segments"]  # no second segment behind a clear surface
+    assert sa["shadow_node_tests"] < sb["shadow_node_tests"]
+    assert differ <= 2e-4
+    # a scene with attenuating glass keeps the chain
+    t5 = HostScene(scene_path("Test5"), FIXTURES)
+    assert DeviceScene(t5, 0).info()["shadow_any_hit"] == 0
