@@ -108,6 +108,50 @@ def cpu_baseline(args, rays_per_sample, shadow_per_sample):
         return {"value": None, "unit": "Mrays/s", "cores": cores, "kind": "unavailable", "sample": str(e)}
 
 
+def caller_times(args, hs, ds, cam, cfg, scene_create, load_scene, device, rays_per_frame):
+    """What a caller of the drop-in sees around the frames `value` is made of (none of it is in `value`):
+    scene set-up with either BVH builder (flatten on the host, then mirt_scene_create), one frame through
+    mirt_render into pageable host memory, and the wall clock of the whole command line."""
+    from raytracer_amd import DeviceScene
+    out = {"scene_create_ms": scene_create}
+    try:
+        other = "host" if args.builder == "device" else "device"
+        h2, flatten_ms = load_scene(other == "host")
+        d2 = DeviceScene(h2, device, builder=other)
+        i2 = d2.info()
+        scene_create[other] = {"flatten_ms": flatten_ms, "create_ms": i2["create_ms"], "tree_ms": i2["tree_ms"]}
+        d2.close()
+        h2.close()
+    except Exception as e:  # the device builder refuses scenes with planes
+        scene_create["device" if args.builder == "host" else "host"] = {"unavailable": str(e)[:200]}
+    cfg.kernel_timing = 0
+    ds.render(cam, cfg, args.width, args.height, args.spp)  # sizes the staging memory
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        ds.render(cam, cfg, args.width, args.height, args.spp)
+    out["host_frame_ms"] = (time.perf_counter() - t0) / n * 1e3
+    out["host_frame_mrays_per_s"] = rays_per_frame / out["host_frame_ms"] / 1e3
+    cli = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+    if os.path.exists(cli) and not args.scene.startswith("synthetic:"):
+        with tempfile.TemporaryDirectory() as tmp:
+            cmd = [cli, "--scene", os.path.join("ASCII", f"{args.scene}.txt"), "--resolution", str(args.width),
+                   str(args.height), "--samples", str(args.spp), "--max-depth", str(args.max_depth), "--binary-ppm",
+                   "--output", os.path.join(tmp, "cli.ppm")]
+            if args.glossy_reflection:
+                cmd += ["--glossy-reflection", str(args.glossy_reflection)]
+            if args.soft_shadows is not None:
+                cmd += ["--soft-shadows", str(args.soft_shadows)]
+            if args.depth_of_field:
+                cmd += ["--depth-of-field", str(args.depth_of_field[0]), str(args.depth_of_field[1])]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=os.path.join(ROOT, "fixtures"), capture_output=True, text=True)
+            out["cli_wall_s"] = time.perf_counter() - t0 if r.returncode == 0 else None
+            m = re.search(r"Render time seconds=([0-9.]+)", r.stdout + r.stderr)
+            out["cli_render_s"] = float(m.group(1)) if m else None
+    return out
+
+
 # BASELINE.json configs[1..4]: argument defaults per preset (explicit flags still override)
 PRESETS = {
     "cfg2": dict(scene="Test5", width=1920, height=1080, spp=16, max_depth=5),
@@ -147,6 +191,10 @@ def main():
     ap.add_argument("--depth-of-field", type=float, nargs=2, default=None, metavar=("FSTOP", "FOCUS"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, choices=(1, 2, 3, 4), default=2)
+    ap.add_argument("--builder", choices=("host", "device"), default=None,
+                    help="where the BVH is built (default: host; the generated cloud: device)")
+    ap.add_argument("--no-caller-times", action="store_true",
+                    help="skip the figures outside `value`: the other builder's scene creation, mirt_render into host memory, the CLI")
     args = ap.parse_args()
     for k, v in PRESETS[args.config].items():
         if getattr(args, k) is None:
@@ -181,11 +229,27 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    if args.scene.startswith("synthetic:"):
-        hs = HostScene.synthetic(int(args.scene.split(":")[1]))
-    else:
-        hs = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{args.scene}.txt"))
-    ds = DeviceScene(hs, local_rank)
+    synthetic = args.scene.startswith("synthetic:")
+    if args.builder is None:
+        # the generated cloud has no planes: its tree is built on the GPU (12 ms against more than a second
+        # on the host); the bundled scenes keep the reference's tree
+        args.builder = "device" if synthetic else "host"
+
+    def load_scene(build_tree):
+        t0 = time.perf_counter()
+        if synthetic:
+            h = HostScene.synthetic(int(args.scene.split(":")[1]), build_tree=build_tree)
+            flatten_ms = h.flatten_ms  # (the generation of the cloud itself is not part of a scene's set-up)
+        else:
+            h = HostScene(os.path.join(ROOT, "fixtures", "ASCII", f"{args.scene}.txt"), build_tree=build_tree)
+            flatten_ms = (time.perf_counter() - t0) * 1e3  # parse + flatten
+        return h, flatten_ms
+
+    hs, flatten_ms = load_scene(args.builder == "host")
+    ds = DeviceScene(hs, local_rank, builder=args.builder)
+    scene_info = ds.info()
+    scene_create = {args.builder: {"flatten_ms": flatten_ms, "create_ms": scene_info["create_ms"],
+                                   "tree_ms": scene_info["tree_ms"]}}
     cam, _ = hs.camera(0, dof=tuple(args.depth_of_field) if args.depth_of_field else None)
     over = dict(max_ray_depth=args.max_depth, glossy_samples=args.glossy_reflection)
     if args.soft_shadows is not None:
@@ -349,7 +413,9 @@ def main():
             "data": ("synthetic" if args.scene.startswith("synthetic:") else "fixture")
                     + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if world > 1 and rehearsal else ""),
             "config": {"workload": workload, "preset": args.config, "tile": tile if world > 1 else None,
-                       "parallelism": f"tiles/{world}", "frames_in_flight": depth},
+                       "parallelism": f"tiles/{world}", "frames_in_flight": depth, "bvh_builder": args.builder,
+                       "traversal": {1: "packet", 2: "lane", 3: "ordered", 4: "wide"}[scene_info["traversal"]],
+                       "shadow_any_hit": bool(scene_info["shadow_any_hit"])},
             "mrays_all_per_s": rays_all / elapsed / 1e6,
             "rays_per_sample": rays_ps / max(tot["primary_rays"], 1),
             "shadow_segments_per_sample": tot["shadow_segments"] / max(tot["primary_rays"], 1),
@@ -370,6 +436,8 @@ def main():
                                  "/ launch time / 8 TB/s; algorithmic_gbs charges every node and primitive test as "
                                  "memory traffic and is not a fraction of anything (the scene stays in cache)"},
         }
+        if world == 1 and not args.no_caller_times:
+            line["caller"] = caller_times(args, hs, ds, cam, cfg, scene_create, load_scene, local_rank, rays_ps / steps)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, line["rays_per_sample"], line["shadow_segments_per_sample"])
         print(json.dumps(line), flush=True)

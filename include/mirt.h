@@ -222,7 +222,8 @@ void mirt_scene_destroy(mirt_scene *scene);
 enum { MIRT_BUILDER_HOST = 0, MIRT_BUILDER_DEVICE = 1 };
 typedef struct mirt_build_options {
   int32_t builder;    /* MIRT_BUILDER_* */
-  int32_t leaf_size;  /* DEVICE: most primitives of a leaf, 1 .. 4; 0: default (2 = MAX_LEAF_SIZE, Bvh.h:12) */
+  int32_t leaf_size;  /* DEVICE: most primitives of a leaf, 1 .. 4 (the reference: MAX_LEAF_SIZE 2, Bvh.h:12); 0: default
+                         (1: a primitive test costs many box tests, measured fastest on a million primitives) */
   int32_t reserved[6];
 } mirt_build_options;
 /* mirt_scene_create with a choice of builder; options == NULL is mirt_scene_create. */
@@ -263,9 +264,13 @@ int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_config 
                 int height, int spp, double *rgb_out, mirt_stats *stats);
 
 /* The same frame, sharded for one-process-per-GPU rendering: the image is cut into tiles of
- * tile_w x tile_h pixels numbered row-major, and this call renders the tiles t with
- * t % world == rank.  d_rgb_out is a DEVICE pointer (on the scene's device) to
- * mirt_tile_buffer_pixels(...) * 3 doubles: the owned tiles in increasing t, each tile stored
+ * tile_w x tile_h pixels, tiles_x = ceil(width / tile_w) of them per row, and this call renders the tiles
+ * that belong to `rank`: tile (tx, ty) belongs to rank (ty * tiles_x + tx) % world -- except when tiles_x
+ * is a multiple of world (which would hand every rank whole columns of tiles): then to rank
+ * (tx + k * ty) % world with k = round(sqrt(world)), a lattice that spreads a rank's tiles evenly in both
+ * directions; mirt_tile_owner() is that rule.  d_rgb_out is a DEVICE pointer
+ * (on the scene's device) to
+ * mirt_tile_buffer_pixels(...) * 3 doubles: the owned tiles in row-major order, each tile stored
  * row-major as tile_h rows of tile_w pixels (edge tiles are padded; padding is written as 0).
  * With world == 1 and tile_w == width, tile_h == height this is the whole frame, row-major.
  * `stream` is a hipStream_t; the call synchronises it before returning.  NULL selects the engine's own
@@ -276,6 +281,8 @@ int mirt_render_tiles(mirt_scene *scene, const mirt_camera *camera, const mirt_c
                       int width, int height, int spp, int tile_w, int tile_h, int rank, int world,
                       double *d_rgb_out, void *stream, mirt_stats *stats);
 int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int tile_h, int rank, int world);
+/* The rank that renders tile (tx, ty) of a grid tiles_x tiles wide, or -1 for arguments out of range. */
+int mirt_tile_owner(int tx, int ty, int tiles_x, int world);
 
 /* Parity hook: closest hit of the camera ray through every pixel centre at time 0.5, i.e.
  * `intersect_bvh(camera.get_ray(x+.5, y+.5, w, h, .5), root, scene, hit, 1e-5, DBL_MAX)`
@@ -353,7 +360,7 @@ int mirt_scene_set_traversal(mirt_scene *scene, int mode);
 
 /* Several GPUs in one process.  No counterpart in the reference, whose only parallelism is the OpenMP
  * row loop (Raytracer.cpp:525): a group replicates the scene on every device named (one mirt_scene
- * each), mirt_group_render deals the image's 16x16 tiles round-robin (tile t to member t % n), lets
+ * each), mirt_group_render deals the image's 16x16 tiles round-robin (mirt_tile_owner), lets
  * all members render their share at the same time, gathers the shares on the first device with RCCL
  * (ncclSend / ncclRecv over xGMI; hipMemcpyPeerAsync where RCCL is missing or a device is named twice
  * -- mirt_group_transport() names what is in use) and writes the frame to rgb_out (host, as
@@ -369,6 +376,21 @@ const char *mirt_group_transport(const mirt_group *group);
 int mirt_group_set_traversal(mirt_group *group, int mode);
 int mirt_group_render(mirt_group *group, const mirt_camera *camera, const mirt_config *config, int width,
                       int height, int spp, double *rgb_out, mirt_stats *stats, mirt_stats *member_stats);
+/* mirt_group_render in two halves, for frames that follow one another (no counterpart in the reference).
+ * _begin enqueues the whole frame -- every member's share on that member's device, the gather of the
+ * shares behind them, the kernel that puts the tiles in place on the first device -- and returns without
+ * waiting for any device; `slot` (0 .. MIRT_GROUP_SLOTS - 1) names the set of buffers and streams it uses,
+ * so a second frame can be begun while the first is still running.  _end waits for the slot's frame, copies
+ * it to rgb_out when that is not NULL (the read-back runs on a stream of its own: begin frame i + 1 first
+ * and it overlaps that frame's rendering), and fills the statistics as mirt_group_render does.  After _end,
+ * and until the slot's next _begin, mirt_group_frame(group, slot) is the frame in the first device's
+ * memory (height * width * 3 doubles, row-major) for callers that go on working there.  When a call
+ * fails, every member has been waited for and the slot is free again. */
+#define MIRT_GROUP_SLOTS 2
+int mirt_group_render_begin(mirt_group *group, const mirt_camera *camera, const mirt_config *config, int width,
+                            int height, int spp, int slot);
+int mirt_group_render_end(mirt_group *group, int slot, double *rgb_out, mirt_stats *stats, mirt_stats *member_stats);
+const double *mirt_group_frame(const mirt_group *group, int slot);
 
 const char *mirt_last_error(void);
 int mirt_abi_version(void);

@@ -104,7 +104,7 @@ class SceneInfo(C.Structure):
 MIRT_BUILDER_HOST, MIRT_BUILDER_DEVICE = 0, 1
 
 ENGINE_SYMBOLS = [
-    "mirt_scene_create_with", "mirt_scene_get_info", "mirt_scene_update_prims", "mirt_scene_refit",
+    "mirt_tile_owner", "mirt_group_render_begin", "mirt_group_render_end", "mirt_group_frame", "mirt_scene_create_with", "mirt_scene_get_info", "mirt_scene_update_prims", "mirt_scene_refit",
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
     "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal", "mirt_render_tiles_begin", "mirt_render_tiles_end",
     "mirt_last_error", "mirt_abi_version", "mirt_render_tiles_noalloc", "mirt_noalloc_scratch_bytes",
@@ -145,8 +145,13 @@ def _declare_engine(lib):
     lib.mirt_group_set_traversal.argtypes = [C.c_void_p, C.c_int]
     lib.mirt_group_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Config), C.c_int, C.c_int, C.c_int, dp,
                                       C.POINTER(Stats), C.POINTER(Stats)]
+    lib.mirt_group_render_begin.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.mirt_group_render_end.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(Stats), C.POINTER(Stats)]
+    lib.mirt_group_frame.argtypes = [C.c_void_p, C.c_int]
+    lib.mirt_group_frame.restype = C.c_void_p
     lib.mirt_tile_buffer_pixels.argtypes = [C.c_int] * 6
     lib.mirt_tile_buffer_pixels.restype = C.c_int64
+    lib.mirt_tile_owner.argtypes = [C.c_int] * 4
     lib.mirt_trace_ids.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, dp]
     lib.mirt_trace_rays.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp, C.c_double, dp, C.POINTER(C.c_int32), dp, dp]
     lib.mirt_scene_set_traversal.argtypes = [C.c_void_p, C.c_int]

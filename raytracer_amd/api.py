@@ -274,6 +274,27 @@ class DeviceGroup:
         return out, st.as_dict(), [p.as_dict() for p in per]
 
 
+    # the two halves of render(): several frames in flight (mirt_group_render_begin / _end)
+    def render_begin(self, camera, config, width, height, spp, slot=0):
+        _check(self._lib.mirt_group_render_begin(self._h, C.byref(camera), C.byref(config), width, height, spp, slot),
+               "mirt_group_render_begin")
+        self._shape = getattr(self, "_shape", {})
+        self._shape[slot] = (height, width)
+
+    def render_end(self, slot=0, to_host=True):
+        """Waits for the slot's frame; returns (frame or None, summed stats, per-member stats).  With
+        to_host=False the frame stays on the first device: frame_pointer(slot)."""
+        h, w = self._shape[slot]
+        out = np.empty((h, w, 3), dtype=np.float64) if to_host else None
+        st = A.Stats()
+        per = (A.Stats * len(self.devices))()
+        _check(self._lib.mirt_group_render_end(self._h, slot, _dptr(out), C.byref(st), per), "mirt_group_render_end")
+        return out, st.as_dict(), [p.as_dict() for p in per]
+
+    def frame_pointer(self, slot=0):
+        return self._lib.mirt_group_frame(self._h, slot)
+
+
 def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
@@ -296,11 +317,27 @@ def tile_buffer_pixels(width, height, tile_w, tile_h, rank, world):
     return int(A.engine_lib().mirt_tile_buffer_pixels(width, height, tile_w, tile_h, rank, world))
 
 
+def tile_owner(tx, ty, tiles_x, world):
+    """The rank that renders tile (tx, ty): (ty * tiles_x + tx) % world, or (tx + k * ty) % world with
+    k = round(sqrt(world)) when tiles_x is a multiple of world (mirt_tile_owner's rule, restated so that it
+    also runs without the library)."""
+    if world > 1 and tiles_x % world == 0:
+        return (tx + tile_lattice_step(world) * ty) % world
+    return (ty * tiles_x + tx) % world
+
+
+def tile_lattice_step(world):
+    k = 1
+    while (2 * k + 1) ** 2 <= 4 * world:
+        k += 1
+    return k
+
+
 def owned_tiles(width, height, tile_w, tile_h, rank, world):
     """Tile indices (row-major) rendered by `rank`, in buffer order."""
     tiles_x = (width + tile_w - 1) // tile_w
     tiles_y = (height + tile_h - 1) // tile_h
-    return list(range(rank, tiles_x * tiles_y, world))
+    return [t for t in range(tiles_x * tiles_y) if tile_owner(t % tiles_x, t // tiles_x, tiles_x, world) == rank]
 
 
 def scatter_tiles(frame, buf, width, height, tile_w, tile_h, rank, world):

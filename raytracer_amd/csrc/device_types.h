@@ -147,6 +147,7 @@ struct DFrame {
   mirt_config cfg;
   int32_t width, height, spp;
   int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world;
+  int32_t stagger;             // tile ownership is staggered row by row (tile_stagger)
   int32_t blocks_x, blocks_y;  // 16x16-pixel thread blocks per tile
   int32_t n_slots;             // tiles owned by this rank
   uint32_t plane;              // pixels of this rank's tile buffer: the accumulator is three planes of that many doubles
@@ -161,6 +162,39 @@ struct DLightFrame {
   // area lights: the basis Light::sample_point (Light.h:44-52) builds on every call, built once
   double right[3], up[3];
 };
+
+// Which rank renders which tile.  Tile (tx, ty) of the row-major tile grid belongs to rank
+// (ty * tiles_x + tx) % world -- unless tiles_x is a multiple of world, where that would give every rank
+// whole columns of tiles (a systematic imbalance on anything with vertical structure).  Then the owner is
+// (tx + k * ty) % world with k = round(sqrt(world)): the tiles of one rank form a lattice whose points are
+// about sqrt(world) tiles apart in every direction (k = 1, plain diagonals, leaves them 1.4 tiles apart
+// along the diagonal and `world` apart across it, and a feature a few tiles wide then lands on some
+// ranks more than on others).  A rank's buffer holds its tiles in row-major order.
+#ifdef __HIPCC__
+#define MIRT_HD __host__ __device__
+#else
+#define MIRT_HD
+#endif
+// 0: the row-major rule; otherwise the multiplier k of the lattice rule
+MIRT_HD static inline int tile_stagger(int tiles_x, int world) {
+  if (world <= 1 || tiles_x % world != 0) return 0;
+  int k = 1;
+  while ((2 * k + 1) * (2 * k + 1) <= 4 * world) ++k;  // round(sqrt(world))
+  return k;
+}
+MIRT_HD static inline int tile_owner(int tx, int ty, int tiles_x, int world, int stagger) {
+  return stagger ? (tx + stagger * ty) % world : (ty * tiles_x + tx) % world;
+}
+// the row-major index of the tile in slot `slot` of rank `rank`'s buffer
+MIRT_HD static inline int tile_of_slot(int slot, int rank, int tiles_x, int world, int stagger) {
+  if (!stagger) return rank + slot * world;
+  const int per_row = tiles_x / world, ty = slot / per_row, j = slot % per_row;
+  return ty * tiles_x + ((rank - stagger * ty) % world + world) % world + j * world;
+}
+// the slot of tile (tx, ty) in its owner's buffer
+MIRT_HD static inline int tile_slot(int tx, int ty, int tiles_x, int world, int stagger) {
+  return stagger ? ty * (tiles_x / world) + tx / world : (ty * tiles_x + tx) / world;
+}
 
 // Ray queue, structure of arrays; one queue per ray-tree depth.
 // Queues are cut into QUEUE_SHARDS independent shards, each with its own tail counter on its own
@@ -278,7 +312,7 @@ struct RaysArgs {
 struct DeinterleaveArgs {
   const double *gathered;
   double *frame;
-  int32_t width, height, tile, tiles_x, world, pad;
+  int32_t width, height, tile, tiles_x, world, stagger;
   uint64_t offset[MIRT_GROUP_MAX];  // in doubles: where member r's tiles start in `gathered`
 };
 void launch_deinterleave(unsigned grid, void *stream, const DeinterleaveArgs &a);

@@ -575,6 +575,12 @@ size_t env_size(const char *name, size_t dflt) {
   return x > 0 ? (size_t)x : dflt;
 }
 
+bool env_flag(const char *name, bool dflt) {  // "0" switches off, anything else on
+  const char *v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  return !(v[0] == '0' && v[1] == 0);
+}
+
 // Camera basis of Camera::get_ray (Camera.cpp:32-58, :91-92).
 DCamera device_camera(const mirt_camera &c, int width, int height) {
   DCamera d;
@@ -842,7 +848,7 @@ int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_optio
     HIP_TRY(upload(sc->leaf_tagged, std::vector<int32_t>()));
     sc->bvh_depth = 0;
     sc->dbvh.reset(new DeviceBvh);
-    const uint32_t leaf = opts.leaf_size ? (uint32_t)opts.leaf_size : (uint32_t)env_size("MIRT_DEVICE_LEAF", 2);
+    const uint32_t leaf = opts.leaf_size ? (uint32_t)opts.leaf_size : (uint32_t)env_size("MIRT_DEVICE_LEAF", 1);
     const int be = sc->dbvh->build(sc->stream, sc->prims.as<DPrim>(), sc->motion_ends.as<double>(),
                                    sc->transparency.as<double>(), (uint32_t)s.n_prims, leaf);
     if (be != 0)
@@ -1014,6 +1020,11 @@ MIRT_API int64_t mirt_tile_buffer_pixels(int width, int height, int tile_w, int 
   return mine * tile_w * tile_h;
 }
 
+MIRT_API int mirt_tile_owner(int tx, int ty, int tiles_x, int world) {
+  if (tx < 0 || ty < 0 || tiles_x <= 0 || tx >= tiles_x || world <= 0) return -1;
+  return tile_owner(tx, ty, tiles_x, world, tile_stagger(tiles_x, world));
+}
+
 namespace {
 
 // The orthonormal basis around an area light's normal (Light.h:44-52), same expressions in the same
@@ -1058,6 +1069,7 @@ FrameShape frame_shape(const mirt_camera &camera, const mirt_config &config, int
   fr.tiles_y = (height + tile_h - 1) / tile_h;
   fr.rank = rank;
   fr.world = world;
+  fr.stagger = tile_stagger(fr.tiles_x, world);
   fr.blocks_x = (tile_w + 15) / 16;
   fr.blocks_y = (tile_h + 15) / 16;
   f.tiles = (int64_t)fr.tiles_x * fr.tiles_y;
@@ -1130,7 +1142,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   const bool streaming = sc->walk == WALK_WIDE && sc->stream_kernels && !ws->fixed;
   // ... and their shadow items are queued by light (2 to 8 lights): light li owns `shadow_per` of the shards
   uint32_t shadow_groups = 1, shadow_per = QUEUE_SHARDS;
-  if (streaming && n_lights >= 2 && n_lights <= 8 && env_size("MIRT_SHADOW_BY_LIGHT", 1) == 1) {
+  if (streaming && n_lights >= 2 && n_lights <= 8 && env_flag("MIRT_SHADOW_BY_LIGHT", true)) {
     shadow_groups = (uint32_t)n_lights;
     shadow_per = QUEUE_SHARDS / shadow_groups;
   }
@@ -1308,6 +1320,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
         HIP_TRY(hipEventRecord(t.b, stream));
         ws->timed.push_back(t);
       }
+      ws->launches++;
 
       ShadowArgs sa;
       std::memset(&sa, 0, sizeof sa);
@@ -1335,7 +1348,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
         HIP_TRY(hipEventRecord(ts.b, stream));
         ws->timed.push_back(ts);
       }
-      ws->launches += 2;
+      ws->launches++;
     }
   }
 
@@ -1404,8 +1417,9 @@ int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
     if (levels > 0 && shape.total_blocks > 0) {
       // samples of the pixels this rank owns
       uint64_t px = 0;
-      for (int64_t t = ws->rank; t < shape.tiles; t += ws->world) {
-        const int tx = (int)(t % shape.fr.tiles_x), ty = (int)(t / shape.fr.tiles_x);
+      for (int slot = 0; slot < shape.fr.n_slots; ++slot) {
+        const int t = tile_of_slot(slot, ws->rank, shape.fr.tiles_x, ws->world, shape.fr.stagger);
+        const int tx = t % shape.fr.tiles_x, ty = t / shape.fr.tiles_x;
         px += (uint64_t)std::min(ws->tile_w, ws->width - tx * ws->tile_w) *
               std::min(ws->tile_h, ws->height - ty * ws->tile_h);
       }

@@ -72,10 +72,18 @@ constexpr int kNcclDouble = 8;  // ncclFloat64 (rccl.h)
 struct Member {
   int device = 0;
   mirt_scene *scene = nullptr;
-  hipStream_t stream = nullptr;
-  double *tiles = nullptr;  // this member's tiles, on its device
-  size_t tiles_bytes = 0;
   comm_t comm = nullptr;
+  // per frame in flight (slot): a stream, this member's tiles on its device, and "tiles rendered"
+  hipStream_t stream[MIRT_GROUP_SLOTS] = {};
+  double *tiles[MIRT_GROUP_SLOTS] = {};
+  size_t tiles_bytes[MIRT_GROUP_SLOTS] = {};
+  hipEvent_t rendered[MIRT_GROUP_SLOTS] = {};
+};
+
+struct Pending {
+  bool active = false;
+  int width = 0, height = 0;
+  std::vector<size_t> off;  // in doubles, within `gathered`: where each member's tiles start
 };
 
 }  // namespace
@@ -85,12 +93,12 @@ struct mirt_group {
   Rccl rccl;
   bool use_rccl = false;
   std::string transport;
-  // on the root (member 0) device: every member's tiles side by side, and the frame
-  double *gathered = nullptr;
-  size_t gathered_bytes = 0;
-  double *frame = nullptr;
-  size_t frame_bytes = 0;
-  hipEvent_t done[MIRT_GROUP_MAX] = {};
+  // on the root (member 0) device, per slot: every member's tiles side by side, and the frame
+  double *gathered[MIRT_GROUP_SLOTS] = {};
+  size_t gathered_bytes[MIRT_GROUP_SLOTS] = {};
+  double *frame[MIRT_GROUP_SLOTS] = {};
+  size_t frame_bytes[MIRT_GROUP_SLOTS] = {};
+  Pending pending[MIRT_GROUP_SLOTS];
 };
 
 namespace {
@@ -106,6 +114,65 @@ int grow(int device, double **p, size_t *have, size_t want) {
   return MIRT_OK;
 }
 
+// Enqueues, behind the members' frames of `slot`: their tiles to the root device, then the kernel that
+// puts the tiles where they belong in the frame.  Nothing here waits for a device.
+int enqueue_gather(mirt_group *g, int slot) {
+  const int n = static_cast<int>(g->m.size());
+  const Pending &pd = g->pending[slot];
+  Member &root = g->m[0];
+  if (g->use_rccl) {
+    // one group: the root posts a receive per member, every member posts its send on the stream its
+    // frame runs on, so each send starts when that member's tiles are complete
+    int rc = g->rccl.GroupStart();
+    for (int i = 0; i < n && rc == 0; ++i) {
+      const size_t count = pd.off[i + 1] - pd.off[i];
+      if (!count) continue;
+      rc = g->rccl.Recv(g->gathered[slot] + pd.off[i], count, kNcclDouble, i, root.comm, root.stream[slot]);
+      if (rc == 0) rc = g->rccl.Send(g->m[i].tiles[slot], count, kNcclDouble, 0, g->m[i].comm, g->m[i].stream[slot]);
+    }
+    const int rc_end = g->rccl.GroupEnd();
+    if (rc == 0) rc = rc_end;
+    if (rc != 0) return mirt_fail(MIRT_ERR_DEVICE, "RCCL gather: %s", g->rccl.GetErrorString(rc));
+  } else {
+    for (int i = 0; i < n; ++i) {
+      const size_t bytes = (pd.off[i + 1] - pd.off[i]) * sizeof(double);
+      if (!bytes) continue;
+      if (i > 0) {  // the root's stream waits for member i's frame (member 0's frame is on that stream already)
+        HIP_TRY(hipSetDevice(g->m[i].device));
+        HIP_TRY(hipEventRecord(g->m[i].rendered[slot], g->m[i].stream[slot]));
+        HIP_TRY(hipSetDevice(root.device));
+        HIP_TRY(hipStreamWaitEvent(root.stream[slot], g->m[i].rendered[slot], 0));
+      }
+      HIP_TRY(hipSetDevice(root.device));
+      HIP_TRY(hipMemcpyPeerAsync(g->gathered[slot] + pd.off[i], root.device, g->m[i].tiles[slot], g->m[i].device, bytes,
+                                 root.stream[slot]));
+    }
+  }
+  HIP_TRY(hipSetDevice(root.device));
+  DeinterleaveArgs da;
+  std::memset(&da, 0, sizeof da);
+  da.gathered = g->gathered[slot];
+  da.frame = g->frame[slot];
+  da.width = pd.width;
+  da.height = pd.height;
+  da.tile = MIRT_GROUP_TILE;
+  da.tiles_x = (pd.width + MIRT_GROUP_TILE - 1) / MIRT_GROUP_TILE;
+  da.world = n;
+  da.stagger = tile_stagger(da.tiles_x, n);
+  for (int i = 0; i < n; ++i) da.offset[i] = pd.off[i];
+  launch_deinterleave(static_cast<unsigned>((static_cast<size_t>(pd.width) * pd.height + 255) / 256), root.stream[slot], da);
+  HIP_TRY(hipGetLastError());
+  return MIRT_OK;
+}
+
+// Waits for whatever the group has enqueued for `slot` (after an error: nothing may still be running
+// when the caller is told).
+void drain(mirt_group *g, int slot) {
+  for (Member &mb : g->m) {
+    if (hipSetDevice(mb.device) == hipSuccess && mb.stream[slot]) (void)hipStreamSynchronize(mb.stream[slot]);
+  }
+}
+
 }  // namespace
 
 MIRT_API void mirt_group_destroy(mirt_group *g) {
@@ -113,17 +180,21 @@ MIRT_API void mirt_group_destroy(mirt_group *g) {
   for (Member &mb : g->m) {
     (void)hipSetDevice(mb.device);
     if (mb.comm && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(mb.comm);
-    if (mb.tiles) (void)hipFree(mb.tiles);
-    if (mb.stream) (void)hipStreamDestroy(mb.stream);
+    for (int s = 0; s < MIRT_GROUP_SLOTS; ++s) {
+      if (mb.tiles[s]) (void)hipFree(mb.tiles[s]);
+      if (mb.stream[s]) (void)hipStreamDestroy(mb.stream[s]);
+      if (mb.rendered[s]) (void)hipEventDestroy(mb.rendered[s]);
+    }
     mirt_scene_destroy(mb.scene);
   }
   if (!g->m.empty()) {
     (void)hipSetDevice(g->m[0].device);
-    if (g->gathered) (void)hipFree(g->gathered);
-    if (g->frame) (void)hipFree(g->frame);
+    for (int s = 0; s < MIRT_GROUP_SLOTS; ++s) {
+      if (g->gathered[s]) (void)hipFree(g->gathered[s]);
+      if (g->frame[s]) (void)hipFree(g->frame[s]);
+    }
   }
-  for (hipEvent_t e : g->done)
-    if (e) (void)hipEventDestroy(e);
+  if (g->rccl.lib) (void)dlclose(g->rccl.lib);
   delete g;
 }
 
@@ -148,8 +219,10 @@ MIRT_API int mirt_group_create(const mirt_scene_desc *desc, const int *devices, 
     mb.device = devices[i];
     if (int rc = mirt_scene_create(desc, devices[i], &mb.scene)) return rc;  // a replica per member
     HIP_TRY(hipSetDevice(mb.device));
-    HIP_TRY(hipStreamCreateWithFlags(&mb.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming));
+    for (int s = 0; s < MIRT_GROUP_SLOTS; ++s) {
+      HIP_TRY(hipStreamCreateWithFlags(&mb.stream[s], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&mb.rendered[s], hipEventDisableTiming));
+    }
   }
   // RCCL: one communicator per member, all made by this process.  It needs distinct devices.
   bool distinct = true;
@@ -188,38 +261,87 @@ MIRT_API int mirt_group_set_traversal(mirt_group *g, int mode) {
   return MIRT_OK;
 }
 
-MIRT_API int mirt_group_render(mirt_group *g, const mirt_camera *camera, const mirt_config *config, int width,
-                               int height, int spp, double *rgb_out, mirt_stats *stats, mirt_stats *member_stats) {
-  if (!g || !camera || !config || !rgb_out) return mirt_fail(MIRT_ERR_INVALID, "NULL argument");
+MIRT_API int mirt_group_render_begin(mirt_group *g, const mirt_camera *camera, const mirt_config *config, int width,
+                                     int height, int spp, int slot) {
+  if (!g || !camera || !config) return mirt_fail(MIRT_ERR_INVALID, "NULL argument");
   if (width <= 0 || height <= 0 || spp <= 0) return mirt_fail(MIRT_ERR_INVALID, "width, height and spp must be positive");
+  if (slot < 0 || slot >= MIRT_GROUP_SLOTS) return mirt_fail(MIRT_ERR_INVALID, "slot must be 0 .. %d", MIRT_GROUP_SLOTS - 1);
+  Pending &pd = g->pending[slot];
+  if (pd.active) return mirt_fail(MIRT_ERR_INVALID, "slot %d still holds a frame: call mirt_group_render_end first", slot);
   const int n = static_cast<int>(g->m.size());
   const int tile = MIRT_GROUP_TILE;
   Member &root = g->m[0];
-
-  // every member's share, enqueued on its own device and stream: they render at the same time
-  std::vector<size_t> off(n + 1, 0);  // in doubles, within `gathered`
+  try {
+    pd.off.assign(n + 1, 0);
+  } catch (const std::exception &) {
+    return mirt_fail(MIRT_ERR_MEMORY, "out of host memory");
+  }
   for (int i = 0; i < n; ++i) {
     Member &mb = g->m[i];
     const size_t px = static_cast<size_t>(mirt_tile_buffer_pixels(width, height, tile, tile, i, n));
-    off[i + 1] = off[i] + px * 3;
-    if (int rc = grow(mb.device, &mb.tiles, &mb.tiles_bytes, std::max<size_t>(px * 3 * sizeof(double), 64))) return rc;
-  }
-  if (int rc = grow(root.device, &g->gathered, &g->gathered_bytes, std::max<size_t>(off[n] * sizeof(double), 64))) return rc;
-  const size_t frame_bytes = static_cast<size_t>(width) * height * 3 * sizeof(double);
-  if (int rc = grow(root.device, &g->frame, &g->frame_bytes, frame_bytes)) return rc;
-  for (int i = 0; i < n; ++i) {
-    Member &mb = g->m[i];
-    if (int rc = mirt_render_tiles_begin(mb.scene, camera, config, width, height, spp, tile, tile, i, n, mb.tiles,
-                                         mb.stream, 0))
+    pd.off[i + 1] = pd.off[i] + px * 3;
+    if (int rc = grow(mb.device, &mb.tiles[slot], &mb.tiles_bytes[slot], std::max<size_t>(px * 3 * sizeof(double), 64)))
       return rc;
   }
-  // wait for every member's frame (a member whose queues overflowed renders it again here), then move
+  if (int rc = grow(root.device, &g->gathered[slot], &g->gathered_bytes[slot], std::max<size_t>(pd.off[n] * sizeof(double), 64)))
+    return rc;
+  const size_t frame_bytes = static_cast<size_t>(width) * height * 3 * sizeof(double);
+  if (int rc = grow(root.device, &g->frame[slot], &g->frame_bytes[slot], frame_bytes)) return rc;
+  pd.width = width;
+  pd.height = height;
+  // every member's share, enqueued on its own device and stream: they render at the same time
+  const char *hook = std::getenv("MIRT_GROUP_TEST_FAIL_MEMBER");  // test hook: this member's begin fails
+  const int fail_member = hook && *hook ? std::atoi(hook) : -1;
+  for (int i = 0; i < n; ++i) {
+    Member &mb = g->m[i];
+    int rc = i == fail_member ? mirt_fail(MIRT_ERR_DEVICE, "member %d: failure injected by MIRT_GROUP_TEST_FAIL_MEMBER", i)
+                              : mirt_render_tiles_begin(mb.scene, camera, config, width, height, spp, tile, tile, i, n,
+                                                        mb.tiles[slot], mb.stream[slot], slot);
+    if (rc != MIRT_OK) {
+      // the members already begun hold a frame in this slot: finish them, or the slot stays taken for good
+      const std::string why = mirt_last_error();
+      for (int j = 0; j < i; ++j) (void)mirt_render_tiles_end(g->m[j].scene, slot, nullptr);
+      return mirt_fail(rc, "%s", why.c_str());
+    }
+  }
+  if (int rc = enqueue_gather(g, slot)) {
+    const std::string why = mirt_last_error();
+    for (int j = 0; j < n; ++j) (void)mirt_render_tiles_end(g->m[j].scene, slot, nullptr);
+    drain(g, slot);
+    return mirt_fail(rc, "%s", why.c_str());
+  }
+  pd.active = true;
+  return MIRT_OK;
+}
+
+MIRT_API int mirt_group_render_end(mirt_group *g, int slot, double *rgb_out, mirt_stats *stats, mirt_stats *member_stats) {
+  if (!g) return mirt_fail(MIRT_ERR_INVALID, "NULL group");
+  if (slot < 0 || slot >= MIRT_GROUP_SLOTS) return mirt_fail(MIRT_ERR_INVALID, "slot must be 0 .. %d", MIRT_GROUP_SLOTS - 1);
+  Pending &pd = g->pending[slot];
+  if (!pd.active) return mirt_fail(MIRT_ERR_INVALID, "no frame in flight in slot %d", slot);
+  pd.active = false;
+  const int n = static_cast<int>(g->m.size());
+  Member &root = g->m[0];
+  // wait for every member's frame (a member whose queues overflowed renders it again here); every member
+  // is waited for even after one has failed, so that no slot stays taken
   mirt_stats total;
   std::memset(&total, 0, sizeof total);
+  int first_rc = MIRT_OK;
+  std::string why;
+  bool redone = false;
   for (int i = 0; i < n; ++i) {
     mirt_stats st;
-    if (int rc = mirt_render_tiles_end(g->m[i].scene, 0, &st)) return rc;
+    std::memset(&st, 0, sizeof st);
+    const int rc = mirt_render_tiles_end(g->m[i].scene, slot, &st);
+    if (rc != MIRT_OK) {
+      if (first_rc == MIRT_OK) {
+        first_rc = rc;
+        why = mirt_last_error();
+      }
+      continue;
+    }
     if (member_stats) member_stats[i] = st;
+    redone = redone || st.frame_attempts > 1;
     total.primary_rays += st.primary_rays;
     total.secondary_rays += st.secondary_rays;
     total.shadow_segments += st.shadow_segments;
@@ -235,46 +357,41 @@ MIRT_API int mirt_group_render(mirt_group *g, const mirt_camera *camera, const m
     total.trace_kernel_launches += st.trace_kernel_launches;
     total.shadow_kernel_launches += st.shadow_kernel_launches;
   }
-  if (g->use_rccl) {
-    // one group: the root posts a receive per member, every member posts its send
-    int rc = g->rccl.GroupStart();
-    for (int i = 0; i < n && rc == 0; ++i) {
-      const size_t count = off[i + 1] - off[i];
-      if (!count) continue;
-      rc = g->rccl.Recv(g->gathered + off[i], count, kNcclDouble, i, root.comm, root.stream);
-      if (rc == 0) rc = g->rccl.Send(g->m[i].tiles, count, kNcclDouble, 0, g->m[i].comm, g->m[i].stream);
-    }
-    const int rc_end = g->rccl.GroupEnd();
-    if (rc == 0) rc = rc_end;
-    if (rc != 0) return mirt_fail(MIRT_ERR_DEVICE, "RCCL gather: %s", g->rccl.GetErrorString(rc));
-  } else {
-    for (int i = 0; i < n; ++i) {
-      const size_t bytes = (off[i + 1] - off[i]) * sizeof(double);
-      if (!bytes) continue;
-      HIP_TRY(hipSetDevice(root.device));
-      HIP_TRY(hipMemcpyPeerAsync(g->gathered + off[i], root.device, g->m[i].tiles, g->m[i].device, bytes, root.stream));
-    }
+  if (first_rc != MIRT_OK) {
+    drain(g, slot);
+    return mirt_fail(first_rc, "%s", why.c_str());
   }
-  // tiles -> frame on the root device, then to the caller's buffer
+  // a frame that was rendered again was gathered half-done the first time
+  if (redone)
+    if (int rc = enqueue_gather(g, slot)) {
+      drain(g, slot);
+      return rc;
+    }
   HIP_TRY(hipSetDevice(root.device));
-  DeinterleaveArgs da;
-  std::memset(&da, 0, sizeof da);
-  da.gathered = g->gathered;
-  da.frame = g->frame;
-  da.width = width;
-  da.height = height;
-  da.tile = tile;
-  da.tiles_x = (width + tile - 1) / tile;
-  da.world = n;
-  for (int i = 0; i < n; ++i) da.offset[i] = off[i];
-  launch_deinterleave(static_cast<unsigned>((static_cast<size_t>(width) * height + 255) / 256), root.stream, da);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(root.stream));
-  if (int rc = mirt_copy_frame_out(root.scene, rgb_out, g->frame, frame_bytes)) return rc;
-  for (int i = 1; i < n; ++i) {  // the senders' streams (RCCL enqueued the sends there)
-    HIP_TRY(hipSetDevice(g->m[i].device));
-    HIP_TRY(hipStreamSynchronize(g->m[i].stream));
+  HIP_TRY(hipStreamSynchronize(root.stream[slot]));
+  if (g->use_rccl)
+    for (int i = 1; i < n; ++i) {  // the senders' streams (RCCL enqueued the sends there)
+      HIP_TRY(hipSetDevice(g->m[i].device));
+      HIP_TRY(hipStreamSynchronize(g->m[i].stream[slot]));
+    }
+  if (rgb_out) {
+    HIP_TRY(hipSetDevice(root.device));
+    if (int rc = mirt_copy_frame_out(root.scene, rgb_out, g->frame[slot],
+                                     static_cast<size_t>(pd.width) * pd.height * 3 * sizeof(double)))
+      return rc;
   }
   if (stats) *stats = total;
   return MIRT_OK;
+}
+
+MIRT_API const double *mirt_group_frame(const mirt_group *g, int slot) {
+  if (!g || slot < 0 || slot >= MIRT_GROUP_SLOTS) return nullptr;
+  return g->frame[slot];
+}
+
+MIRT_API int mirt_group_render(mirt_group *g, const mirt_camera *camera, const mirt_config *config, int width,
+                               int height, int spp, double *rgb_out, mirt_stats *stats, mirt_stats *member_stats) {
+  if (!rgb_out) return mirt_fail(MIRT_ERR_INVALID, "NULL argument");
+  if (int rc = mirt_group_render_begin(g, camera, config, width, height, spp, 0)) return rc;
+  return mirt_group_render_end(g, 0, rgb_out, stats, member_stats);
 }

@@ -738,6 +738,39 @@ DEV void pixel_add(double *accum, uint32_t plane, uint32_t pixel, d3 c) {
   if (c.z != 0.0) unsafeAtomicAdd(p + 2 * (size_t)plane, c.z);
 }
 
+// The same for all lanes of a wave at once (`on`: this lane has something to add), with the terms of
+// neighbouring lanes that go to the same pixel summed in the wave first.  Rays that a glossy hit spawns sit
+// next to one another in their queue (eight siblings at the first bounce, sixty-four cousins at the second)
+// and so do their shadow items: without this a pixel behind two glossy bounces takes a thousand adds to
+// one address per frame, and adds to one address go one at a time -- measured 40 to 70 microseconds per
+// launch of the deep levels, whatever the launch carries.  Costs a ballot when no two neighbours share a pixel.
+// Must be called by all lanes of the wave.
+DEV void pixel_add_wave(double *accum, uint32_t plane, uint32_t pixel, d3 c, bool on) {
+  const int lane = __lane_id();
+  const uint32_t key = on ? pixel : 0xffffffffu;
+  const uint32_t prev = __shfl_up(key, 1);
+  const bool head = lane == 0 || key != prev || !on;
+  const unsigned long long heads = __ballot(head);
+  if (heads == ~0ull) {  // no run longer than one lane
+    if (on) pixel_add(accum, plane, pixel, c);
+    return;
+  }
+  // last lane of this lane's run: the lane before the next head
+  const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+  const int last = above ? lane + __ffsll((long long)above) - 1 : 63;
+  if (!on) c = mk(0, 0, 0);
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const double x = __shfl_down(c.x, off), y = __shfl_down(c.y, off), z = __shfl_down(c.z, off);
+    if (lane + off <= last) {
+      c.x += x;
+      c.y += y;
+      c.z += z;
+    }
+  }
+  if (on && head) pixel_add(accum, plane, pixel, c);
+}
+
 // Appending to the block's shard of a ray queue: the wave counts what it is going to append, one lane
 // reserves the range with a single atomic on the shard's tail (queue_reserve), and every pushing
 // lane writes at the range's start + its rank among the pushers (queue_write).
@@ -823,7 +856,7 @@ DEV d3 reflect_dir(d3 i, d3 n) { return i - n * 2.0 * dot(i, n); }  // Raytracer
 DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int &gy, uint32_t &slot_pixel) {
   const uint32_t per_tile = (uint32_t)(fr.blocks_x * fr.blocks_y);
   const uint32_t slot = block / per_tile, b = block % per_tile;
-  const int tile = fr.rank + (int)slot * fr.world;
+  const int tile = tile_of_slot((int)slot, fr.rank, fr.tiles_x, fr.world, fr.stagger);
   const int tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
   const uint32_t wv = p >> 6, ln = p & 63;
   const int lx = (int)((b % fr.blocks_x) * 16 + (wv & 1) * 8 + (ln & 7));
@@ -880,14 +913,14 @@ DEV bool primary_ray(const TraceArgs &a, uint32_t vb, uint32_t p, RaySeed &r) {
   r.W = mk(1, 1, 1);
   return active;
 }
-// entry j of the launch's input queue
-DEV void queued_ray(const TraceArgs &a, size_t j, RaySeed &r) {
-  r.ro = mk(a.in.ox[j], a.in.oy[j], a.in.oz[j]);
-  r.rd = mk(a.in.dx[j], a.in.dy[j], a.in.dz[j]);
-  r.time = a.in.time[j];
-  r.W = mk(a.in.wr[j], a.in.wg[j], a.in.wb[j]);
-  r.key = a.in.key[j];
-  r.pixel = a.in.pixel[j];
+// entry j of a ray queue
+DEV void queued_ray(const DRayQueue &in, size_t j, RaySeed &r) {
+  r.ro = mk(in.ox[j], in.oy[j], in.oz[j]);
+  r.rd = mk(in.dx[j], in.dy[j], in.dz[j]);
+  r.time = in.time[j];
+  r.W = mk(in.wr[j], in.wg[j], in.wb[j]);
+  r.key = in.key[j];
+  r.pixel = in.pixel[j];
 }
 
 // Unshadowed Blinn-Phong contribution of one light to the pixel (Raytracer.cpp:266-285): `to` from the
@@ -909,21 +942,35 @@ DEV d3 light_term(const L &light, const mirt_config &cfg, d3 to, d3 sn, d3 rd, d
   return c;
 }
 
+// What differs from level to level of a frame's ray tree (wave-uniform).
+struct LevelVar {
+  uint32_t *out_count;     // tails of the queue this level's hits append rays to (unused when they spawn nothing)
+  uint32_t *shadow_count;  // tails of this level's shadow items
+  uint32_t shadow_base;    // where this level's items start in the block's shard of the shadow queue
+  int32_t depth;
+};
+DEV LevelVar level_of(const TraceArgs &a) { return LevelVar{a.out_count, a.shadow_count, 0u, a.depth}; }
+
 // What trace() does with the closest hit (Raytracer.cpp:305-472), for the lanes of the wave with
 // `active` set: background for a miss, local terms without visibility, one shadow work item per
 // contributing light, and the rays the hit spawns.  Must be called by all lanes of the wave; the
 // appends go to shard `shard` of the launch's queues.
 template <bool UV>
-DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const Best<UV> &best, bool active, d3 W,
-                    uint64_t key, uint32_t pixel) {
+DEV void shade_hits(const TraceArgs &a, const DRayQueue &out, const LevelVar &lv, uint32_t shard, const RayL &ray,
+                    const Best<UV> &best, bool active, d3 W, uint64_t key, uint32_t pixel) {
   const DScene &sc = a.sc;
   const mirt_config &cfg = a.fr.cfg;
   const double time = ray.time;
   const bool hit = active && best.prim >= 0;
-  if (active && !hit) pixel_add(a.accum, a.fr.plane, pixel, W * ld3(sc.background));  // Raytracer.cpp:472
+  d3 add = mk(0, 0, 0);  // what this ray adds to its pixel here: the background, or the hit's local terms
+  bool adds = false;
+  if (active && !hit) {  // Raytracer.cpp:472
+    add = W * ld3(sc.background);
+    adds = true;
+  }
 
   // ---- shading of the hit (Raytracer.cpp:305-466), visibility deferred to k_shadow ------------
-  const bool spawn = a.depth + 1 < cfg.max_ray_depth;  // deeper rays would return black (Raytracer.cpp:297)
+  const bool spawn = lv.depth + 1 < cfg.max_ray_depth;  // deeper rays would return black (Raytracer.cpp:297)
   // lanes without a hit bind `m` to material 0 and never read it (a scene may have no primitives at all)
   const mirt_material &m = sc.materials[hit ? sc.prims[best.prim].material : 0];
   Surface<UV> sf = {};
@@ -970,9 +1017,11 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
       local = W * local;
       lit = !(T >= cfg.pure_glass_threshold);  // pure glass is not shaded (Raytracer.cpp:307-311)
       if (lit) local = local + wd * (amb * cfg.ambient_factor);
-      pixel_add(a.accum, a.fr.plane, pixel, local);
+      add = local;
+      adds = true;
     }
   }
+  pixel_add_wave(a.accum, a.fr.plane, pixel, add, adds);
 
   // per-light unshadowed Blinn-Phong terms -> shadow work items (Raytracer.cpp:262-286).  A light
   // that faces away from the shading normal adds exactly zero in the reference, so it gets no item.
@@ -986,7 +1035,7 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
   const bool refl = spawn && hit && R > 0.0 && !pass;
   // a lane without a hit has no material: `m` is only read behind `refl`
   int samples = 1;
-  if (refl && cfg.glossy_samples > 1 && m.glossiness < 0.94 && a.depth < 2) samples = cfg.glossy_samples;
+  if (refl && cfg.glossy_samples > 1 && m.glossiness < 0.94 && lv.depth < 2) samples = cfg.glossy_samples;
   const bool mirror = samples == 1 || (refl && m.glossiness > 0.94);
   const bool push_mirror = refl && mirror, lobe = refl && !mirror;  // a lobe lane appends glossy_samples rays
   const bool push_reflect = spawn && hit && glass, push_refract = spawn && hit && glass && !tir;
@@ -1013,9 +1062,9 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
     uint32_t my_base = 0;
     if (lane < sc.n_lights) {
       const uint32_t cnt = (uint32_t)(packed >> (8 * lane)) & 0xffu;
-      if (cnt) my_base = atomicAdd(a.shadow_count + ((uint32_t)lane * a.shadow_per + sub) * QUEUE_COUNT_STRIDE, cnt);
+      if (cnt) my_base = atomicAdd(lv.shadow_count + ((uint32_t)lane * a.shadow_per + sub) * QUEUE_COUNT_STRIDE, cnt);
     }
-    if (lane == 0 && total) ray_base = atomicAdd(a.out_count + shard * QUEUE_COUNT_STRIDE, total);
+    if (lane == 0 && total) ray_base = atomicAdd(lv.out_count + shard * QUEUE_COUNT_STRIDE, total);
     ray_base = __shfl(ray_base, 0);
     if (packed) {
       const unsigned long long below = (1ull << lane) - 1ull;
@@ -1041,10 +1090,10 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
     }
     uint32_t base = 0;
     if (__lane_id() == 0) {
-      if (items) base = atomicAdd(a.shadow_count + shard * QUEUE_COUNT_STRIDE, items);
-      if (total) ray_base = atomicAdd(a.out_count + shard * QUEUE_COUNT_STRIDE, total);
+      if (items) base = atomicAdd(lv.shadow_count + shard * QUEUE_COUNT_STRIDE, items);
+      if (total) ray_base = atomicAdd(lv.out_count + shard * QUEUE_COUNT_STRIDE, total);
     }
-    base = __shfl(base, 0);
+    base = __shfl(base, 0) + lv.shadow_base;
     ray_base = __shfl(ray_base, 0);
     if (items) {
       const unsigned long long below = (1ull << __lane_id()) - 1ull;
@@ -1077,7 +1126,7 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
     if (metal) cw = cw * tint;
     const d3 org = sf.p + sf.n * eps;
     if (push_mirror)
-      queue_write(a.out, shard, at + (uint32_t)__popcll(m_mirror & below), org, r, time, cw,
+      queue_write(out, shard, at + (uint32_t)__popcll(m_mirror & below), org, r, time, cw,
                   mirt_rng_child_key(key, MIRT_SLOT_GLOSSY), pixel);
     at += n_mirror;
     if (m_lobe) {
@@ -1096,17 +1145,18 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
         sincos(2.0 * M_PI * r2, &sp, &cp);
         d3 dir = unit(u * (st * cp) + v * (st * sp) + w * ct);
         if (dot(dir, sf.n) < 0) dir = r;
-        if (lobe) queue_write(a.out, shard, at + rank, org, dir, time, cws, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY + i), pixel);
-        at += n_lobe;
+        // (a hit's samples next to one another: what they add to the pixel is then summed in the wave first)
+        if (lobe) queue_write(out, shard, at + rank * n_samples + i, org, dir, time, cws, mirt_rng_child_key(key, MIRT_SLOT_GLOSSY + i), pixel);
       }
+      at += n_lobe * n_samples;
     }
     const d3 wbase = pass ? W : W * T;
     if (push_reflect)
-      queue_write(a.out, shard, at + (uint32_t)__popcll(m_reflect & below), sf.p + sf.n * eps, reflect_dir(ray.d, sf.n), time,
+      queue_write(out, shard, at + (uint32_t)__popcll(m_reflect & below), sf.p + sf.n * eps, reflect_dir(ray.d, sf.n), time,
                   tir ? wbase : wbase * fres, mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFLECT), pixel);
     at += n_reflect;
     if (push_refract)
-      queue_write(a.out, shard, at + (uint32_t)__popcll(m_refract & below), sf.p - sf.n * eps,
+      queue_write(out, shard, at + (uint32_t)__popcll(m_refract & below), sf.p - sf.n * eps,
                   perp + sf.n * (-sqrt(maxd(0.0, disc))), time, wbase * (1.0 - fres),
                   mirt_rng_child_key(key, MIRT_SLOT_GLASS_REFRACT), pixel);
   }
@@ -1114,8 +1164,10 @@ DEV void shade_hits(const TraceArgs &a, uint32_t shard, const RayL &ray, const B
 
 // One block of 256 rays: virtual block `vb` of the launch.  `active` and `j` locate the lane's queue
 // entry (unused by PRIMARY, whose virtual blocks are (16x16 pixel block, sample index) pairs).
+// `in` / `out`: the queue the rays come from (unused by PRIMARY) and the one their hits append to.
 template <bool PRIMARY, bool UV, bool MOTION, int WALK>
-DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, unsigned &n_node, unsigned &n_prim) {
+DEV void trace_block(const TraceArgs &a, const DRayQueue &in, const DRayQueue &out, const LevelVar &lv, uint32_t vb,
+                     bool active, size_t j, unsigned &n_node, unsigned &n_prim) {
   const DScene &sc = a.sc;
   const uint32_t shard = vb % QUEUE_SHARDS;  // of the two queues this block appends to
 #if MIRT_PROFILE == 1
@@ -1126,7 +1178,7 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
     progress_mark(a, vb, false);
     active = primary_ray(a, vb, threadIdx.x, r);
   } else {
-    queued_ray(a, j, r);
+    queued_ray(in, j, r);
   }
   const RayL ray = make_ray(r.ro, r.rd, r.time);
   Best<UV> best;
@@ -1153,7 +1205,7 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 #if MIRT_PROFILE == 1
   PROF_MARK(1);
 #endif
-  shade_hits<UV>(a, shard, ray, best, active, W, key, pixel);
+  shade_hits<UV>(a, out, lv, shard, ray, best, active, W, key, pixel);
   if (PRIMARY) progress_mark(a, vb, true);
 #if MIRT_PROFILE == 1
   PROF_MARK(2);
@@ -1166,14 +1218,15 @@ DEV void trace_block(const TraceArgs &a, uint32_t vb, bool active, size_t j, uns
 template <bool PRIMARY, bool UV, bool MOTION, int WALK>
 __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
   unsigned n_node = 0, n_prim = 0;
+  const LevelVar lv = level_of(a);
   if (PRIMARY) {
-    trace_block<true, UV, MOTION, WALK>(a, blockIdx.x, true, 0, n_node, n_prim);
+    trace_block<true, UV, MOTION, WALK>(a, a.in, a.out, lv, blockIdx.x, true, 0, n_node, n_prim);
   } else {
     const WaveView v = wave_view(a.in_count, a.in.shard_cap);
     for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
       size_t j;
       const bool active = view_entry(v, vb, a.in.shard_cap, j);
-      trace_block<false, UV, MOTION, WALK>(a, vb, active, j, n_node, n_prim);
+      trace_block<false, UV, MOTION, WALK>(a, a.in, a.out, lv, vb, active, j, n_node, n_prim);
     }
   }
 #ifndef MIRT_PROFILE
@@ -1333,7 +1386,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_cl
         const bool inside = primary_ray(a, g >> 8, g & 255u, r);
         ok = take && inside;  // numbers that fall outside the image get no hit record; k_shade skips them too
       } else {
-        queued_ray(a, run.slot(g, a.in.shard_cap), r);  // (lanes that took nothing read entry 0 and drop it)
+        queued_ray(a.in, run.slot(g, a.in.shard_cap), r);  // (lanes that took nothing read entry 0 and drop it)
       }
       if (ok) {
         ray = make_ray(r.ro, r.rd, r.time);
@@ -1374,13 +1427,13 @@ __global__ __launch_bounds__(256) void k_shade(const TraceArgs a) {
       const bool inside = primary_ray(a, vb, threadIdx.x, r);
       active = active && inside;
     } else {
-      queued_ray(a, run.slot(active ? g : 0, a.in.shard_cap), r);
+      queued_ray(a.in, run.slot(active ? g : 0, a.in.shard_cap), r);
     }
     const RayL ray = make_ray(r.ro, r.rd, r.time);
     Best<UV> best;
     BEST_IN_LDS(UV, best);
     if (active) hit_load<UV>(a.hits, a.hits_uv, g, best);
-    shade_hits<UV>(a, vb % QUEUE_SHARDS, ray, best, active, r.W, r.key, r.pixel);
+    shade_hits<UV>(a, a.out, level_of(a), vb % QUEUE_SHARDS, ray, best, active, r.W, r.key, r.pixel);
     if (PRIMARY) progress_mark(a, vb, true);
   }
 }
@@ -1499,10 +1552,10 @@ DEV void shadow_block_items(const ShadowArgs &a, const LightTable &lights, bool 
       }
     }
   }
-  if (valid) {
-    const double shadow = total * light_inv_n(lights, a.fr, park_light[tid]);
-    if (!(shadow >= 1.0))  // Raytracer.cpp:264,271
-      pixel_add(a.accum, a.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow));
+  {
+    const double shadow = valid ? total * light_inv_n(lights, a.fr, park_light[tid]) : 1.0;
+    const bool lit = valid && !(shadow >= 1.0);  // Raytracer.cpp:264,271
+    pixel_add_wave(a.accum, a.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]) * (1.0 - shadow), lit);
   }
 #if MIRT_PROFILE == 2
   PROF_MARK(3);
@@ -1880,14 +1933,14 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a) {
 }
 
 
-// Pixel (x, y) of the frame from the compact tile buffer of the member that rendered it: tile t of the
-// row-major tile grid belongs to member t % world and is that member's tile number t / world.
+// Pixel (x, y) of the frame from the compact tile buffer of the member that rendered it (tile_owner,
+// tile_slot in device_types.h).
 __global__ __launch_bounds__(256) void k_deinterleave(const DeinterleaveArgs a) {
   const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
   if (i >= (size_t)a.width * a.height) return;
   const int x = (int)(i % a.width), y = (int)(i / a.width);
-  const int t = (y / a.tile) * a.tiles_x + x / a.tile;
-  const int r = t % a.world, slot = t / a.world;
+  const int tx = x / a.tile, ty = y / a.tile;
+  const int r = tile_owner(tx, ty, a.tiles_x, a.world, a.stagger), slot = tile_slot(tx, ty, a.tiles_x, a.world, a.stagger);
   const double *src = a.gathered + a.offset[r] +
                       3 * ((size_t)slot * a.tile * a.tile + (size_t)(y % a.tile) * a.tile + (x % a.tile));
   a.frame[3 * i] = src[0];

@@ -2,8 +2,9 @@
 replica of the scene; the only exchange is the frame gather at the end (RCCL all-gather over xGMI
 when the tensors are on GPUs; gloo on CPU tensors in the tests).
 
-Tile t (row-major over the image) belongs to rank t % world; a rank's buffer holds its tiles in
-increasing t, each tile as tile_h rows of tile_w pixels (mirt_render_tiles).
+Tile (tx, ty) belongs to rank (ty * tiles_x + tx) % world, or to (tx + k * ty) % world, k = round(sqrt(world)),
+when tiles_x is a multiple of world (mirt_tile_owner); a rank's buffer holds its tiles in row-major order, each tile as
+tile_h rows of tile_w pixels (mirt_render_tiles).
 """
 import torch
 import torch.distributed as dist
@@ -27,9 +28,20 @@ def local_buffer(width, height, tile_w, tile_h, world, device, dtype=torch.float
 def assemble(gathered, width, height, tile_w, tile_h, world):
     """[world * slots * tile_h * tile_w * 3] (rank-major) -> (height, width, 3) frame; tensor ops only."""
     tiles_x, tiles_y, n, slots = tile_counts(width, height, tile_w, tile_h, world)
-    g = gathered.view(world, slots, tile_h, tile_w, 3)
-    g = g.permute(1, 0, 2, 3, 4).reshape(slots * world, tile_h, tile_w, 3)[:n]  # tile order: t = slot*world + rank
-    g = g.view(tiles_y, tiles_x, tile_h, tile_w, 3).permute(0, 2, 1, 3, 4)
+    if world > 1 and tiles_x % world == 0:
+        # staggered rows: rank r's slot (ty, j) is tile tx = (r - k * ty) % world + j * world of row ty
+        from .api import tile_lattice_step
+        k = tile_lattice_step(world)
+        per_row = tiles_x // world
+        g = gathered.view(world, tiles_y, per_row, tile_h, tile_w, 3)
+        ty = torch.arange(tiles_y, device=gathered.device).view(-1, 1, 1)
+        j = torch.arange(per_row, device=gathered.device).view(1, -1, 1)
+        q = torch.arange(world, device=gathered.device).view(1, 1, -1)
+        g = g[(q + k * ty) % world, ty, j]  # [ty, j, q] -> tile tx = j * world + q
+    else:
+        g = gathered.view(world, slots, tile_h, tile_w, 3)
+        g = g.permute(1, 0, 2, 3, 4).reshape(slots * world, tile_h, tile_w, 3)[:n]  # tile order: t = slot*world + rank
+    g = g.reshape(tiles_y, tiles_x, tile_h, tile_w, 3).permute(0, 2, 1, 3, 4)
     return g.reshape(tiles_y * tile_h, tiles_x * tile_w, 3)[:height, :width]
 
 

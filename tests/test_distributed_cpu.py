@@ -11,6 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from raytracer_amd import owned_tiles, scatter_tiles, tile_buffer_pixels
+from raytracer_amd import _abi as A
+from raytracer_amd.api import tile_owner
 from raytracer_amd import distributed as D
 
 
@@ -32,12 +34,19 @@ def expected_frame(width, height):
     return np.stack([xs, ys, xs * ys], axis=-1).astype(np.float64)
 
 
-@pytest.mark.parametrize("width,height,tile,world", [(50, 37, 16, 2), (64, 32, 16, 4), (33, 17, 8, 3), (20, 20, 32, 2)])
+@pytest.mark.parametrize("width,height,tile,world", [(50, 37, 16, 2), (64, 32, 16, 4), (33, 17, 8, 3), (20, 20, 32, 2),
+                                                     (128, 70, 16, 8), (96, 50, 16, 2), (1920, 1080, 16, 8)])
 def test_ownership_and_assemble_single_process(width, height, tile, world):
     tiles_x, tiles_y, n, slots = D.tile_counts(width, height, tile, tile, world)
     owned = [owned_tiles(width, height, tile, tile, r, world) for r in range(world)]
     assert sorted(t for o in owned for t in o) == list(range(n))          # a partition of the tiles
-    assert all(t % world == r for r, o in enumerate(owned) for t in o)    # interleaved
+    lib = A.engine_lib()
+    assert all(lib.mirt_tile_owner(t % tiles_x, t // tiles_x, tiles_x, world) == r == tile_owner(t % tiles_x, t // tiles_x, tiles_x, world)
+               for r, o in enumerate(owned) for t in o)                   # the C ABI's rule
+    if tiles_x % world == 0 and tiles_y > 1:
+        # no rank owns whole columns: the owner of the first column's tile changes from row to row
+        assert all(tile_owner(0, ty, tiles_x, world) != tile_owner(0, ty + 1, tiles_x, world) for ty in range(tiles_y - 1))
+    assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
     gathered = []
     frame = np.zeros((height, width, 3))
     for r in range(world):
