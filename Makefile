@@ -61,7 +61,8 @@ $(LIB)/libmirt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIB)/libmirt.so | $(LIB)
 $(BIN)/raytracer: $(HOST)/main.cpp $(LIB)/libmirt_host.so | $(BIN)
 	$(CXX) $(HOSTFLAGS) -o $@ $(HOST)/main.cpp -L$(LIB) -lmirt_host -lmirt -Wl,-rpath,'$$ORIGIN/../lib'
 
-oracle:
+# (after the engine: oracle/Makefile links the reference's command line against libmirt.so, see integration/)
+oracle: engine
 	$(MAKE) -C oracle all
 
 # ---- render recipes: the settings of the reference's `make test-1 ... test-7`, `test-all` and `benchmark`

@@ -744,6 +744,8 @@ DEV void pixel_add(double *accum, uint32_t plane, uint32_t pixel, d3 c) {
 // and so do their shadow items: without this a pixel behind two glossy bounces takes a thousand adds to
 // one address per frame, and adds to one address go one at a time -- measured 40 to 70 microseconds per
 // launch of the deep levels, whatever the launch carries.  Costs a ballot when no two neighbours share a pixel.
+// (Measured on Test5 with 8 glossy samples, depth 8: an eighth of the 1080p frame 2.15 -> 1.69 ms, the whole
+// frame 10.4 -> 10.9 ms; summing only runs longer than eight lanes: 1.94 and 11.8 ms.)
 // Must be called by all lanes of the wave.
 DEV void pixel_add_wave(double *accum, uint32_t plane, uint32_t pixel, d3 c, bool on) {
   const int lane = __lane_id();
@@ -755,18 +757,17 @@ DEV void pixel_add_wave(double *accum, uint32_t plane, uint32_t pixel, d3 c, boo
     if (on) pixel_add(accum, plane, pixel, c);
     return;
   }
-  // last lane of this lane's run: the lane before the next head
-  const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
-  const int last = above ? lane + __ffsll((long long)above) - 1 : 63;
   if (!on) c = mk(0, 0, 0);
-#pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
+  // bit i of `more`: lanes i + 1 .. i + off all continue lane i's run; doubling steps while any run is that long
+  unsigned long long more = ~heads >> 1;
+  for (int off = 1; more != 0; off <<= 1) {
     const double x = __shfl_down(c.x, off), y = __shfl_down(c.y, off), z = __shfl_down(c.z, off);
-    if (lane + off <= last) {
+    if ((more >> lane) & 1ull) {
       c.x += x;
       c.y += y;
       c.z += z;
     }
+    more &= more >> off;
   }
   if (on && head) pixel_add(accum, plane, pixel, c);
 }

@@ -1,354 +1,12 @@
-// Scene -> flat arrays (see flatten.h).
-//
-// BVH: same tree as the reference builds, because a different topology can change which objects
-// are visible (a zero-thickness box is never hit by BoundingBox::intersect, BoundingBox.h:27) and
-// which object wins an exact tie (leaf order, Bvh.cpp:314-321).  Rule (Bvh.cpp:194-242):
-//   box  = union of the objects' world boxes (get_*_bounding_box, e.g. Sphere.cpp:82-103)
-//   leaf = at most MAX_LEAF_SIZE (2) objects, or depth >= MAX_DEPTH (30)
-//   axis = x only if its extent is strictly the largest, else y if larger than z, else z (Bvh.cpp:89-94)
-//   cut  = std::nth_element at n/2 on the objects' static centres (Bvh.cpp:164-173, :108-145)
-// The reference copies index vectors at every level; here one index array is partitioned in place,
-// which visits the same elements in the same order, and its final state is the leaf list.
+// Scene -> flat arrays for the drop-in classes: instances of the templates of flatten_impl.h.
 #include "flatten.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <fstream>
-#include <iostream>
-#include <map>
-#include <thread>
-#include <utility>
-
-namespace {
-
-constexpr int kMaxLeafSize = 2;
-constexpr int kMaxDepth = 30;
-
-BoundingBox moving_or_static_box(const Shape &s, const BoundingBox &object_box) {
-  if (!s.has_motion) return s.cached_transform.transform_bbox(object_box);
-  BoundingBox b = Transform(s.start_transform).transform_bbox(object_box);
-  b.grow(Transform(s.end_transform).transform_bbox(object_box));
-  return b;
-}
-
-struct Builder {
-  std::vector<BoundingBox> boxes;  // per primitive, world space
-  std::vector<Point> centres;      // per primitive, split key
-  std::vector<int32_t> order;      // primitive indices, partitioned in place
-  FlatScene *out = nullptr;
-  // nodes in the subtree over n objects at depth d: the split rule depends on n and d only, so every
-  // node's index in depth-first order is known before its subtree is built
-  std::map<std::pair<int, int>, int32_t> sizes;
-
-  int32_t subtree_nodes(int n, int depth) {
-    if (n <= kMaxLeafSize || depth >= kMaxDepth) return 1;
-    const auto key = std::make_pair(n, depth);
-    const auto it = sizes.find(key);
-    if (it != sizes.end()) return it->second;
-    const int mid = n / 2;
-    const int32_t v = 1 + subtree_nodes(mid, depth + 1) + subtree_nodes(n - mid, depth + 1);
-    sizes[key] = v;
-    return v;
-  }
-
-  // Builds the subtree of order[lo, hi) into nodes[me ...] (already allocated); returns its depth.
-  // The two halves of a split touch disjoint ranges of `order` and of `nodes`: on large scenes the top
-  // `fork` levels build them on two threads each.
-  int build(int lo, int hi, int depth, int32_t me, int fork) {
-    BoundingBox box{Point(0, 0, 0), Point(0, 0, 0)};
-    for (int i = lo; i < hi; ++i) {
-      if (i == lo) box = boxes[order[i]];
-      else box.grow(boxes[order[i]]);
-    }
-    auto fill = [&](int32_t left, int32_t right, int32_t first, int32_t count) {
-      mirt_node &n = out->nodes[me];
-      n.bmin[0] = box.min.x; n.bmin[1] = box.min.y; n.bmin[2] = box.min.z;
-      n.bmax[0] = box.max.x; n.bmax[1] = box.max.y; n.bmax[2] = box.max.z;
-      n.left = left; n.right = right; n.first = first; n.count = count;
-    };
-    const int n = hi - lo;
-    if (n <= kMaxLeafSize || depth >= kMaxDepth) {
-      fill(-1, -1, lo, n);
-      return 1;
-    }
-    const Vec3 ext = box.max - box.min;
-    const int axis = (ext.x > ext.y && ext.x > ext.z) ? 0 : (ext.y > ext.z ? 1 : 2);
-    const int mid = n / 2;  // n >= 3, so both halves are non-empty
-    std::nth_element(order.begin() + lo, order.begin() + lo + mid, order.begin() + hi,
-                     [this, axis](int32_t a, int32_t b) { return centres[a][axis] < centres[b][axis]; });
-    const int32_t left = me + 1, right = left + sizes_at(mid, depth + 1);
-    int dl = 0, dr = 0;
-    if (fork > 0) {
-      std::thread t([&] { dl = build(lo, lo + mid, depth + 1, left, fork - 1); });
-      dr = build(lo + mid, hi, depth + 1, right, fork - 1);
-      t.join();
-    } else {
-      dl = build(lo, lo + mid, depth + 1, left, 0);
-      dr = build(lo + mid, hi, depth + 1, right, 0);
-    }
-    fill(left, right, 0, 0);
-    return 1 + std::max(dl, dr);
-  }
-  int32_t sizes_at(int n, int depth) const {  // read-only once run() has filled the table
-    if (n <= kMaxLeafSize || depth >= kMaxDepth) return 1;
-    return sizes.at(std::make_pair(n, depth));
-  }
-
-  void run() {
-    const int total = static_cast<int>(order.size());
-    const int32_t n_nodes = subtree_nodes(total, 0);
-    out->nodes.assign(static_cast<std::size_t>(n_nodes), mirt_node{});
-    int fork = total >= 65536 ? 4 : 0;  // 16 threads at the fourth level
-    if (const char *e = std::getenv("MIRT_BVH_FORK_LEVELS")) fork = std::max(0, std::min(6, std::atoi(e)));
-    out->max_depth = build(0, total, 0, 0, fork);
-    out->node_count = n_nodes;
-    out->leaf_count = 0;
-    for (const mirt_node &n : out->nodes) out->leaf_count += n.left < 0 ? 1 : 0;
-  }
-};
-
-void copy3(double *dst, const Vec3 &v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
-void copy16(double *dst, const Mat4 &m) { std::memcpy(dst, m.m, sizeof(double) * 16); }
-
-mirt_prim base_prim(const Shape &s, int type, int material) {
-  mirt_prim p;
-  std::memset(&p, 0, sizeof p);
-  p.type = type;
-  p.visible = s.visible ? 1 : 0;
-  p.has_motion = s.has_motion ? 1 : 0;
-  p.material = material;
-  copy16(p.o2w, s.cached_transform.object_to_world);
-  copy16(p.w2o, s.cached_transform.world_to_object);
-  copy16(p.m0, s.start_transform);
-  copy16(p.m1, s.end_transform);
-  return p;
-}
-
-// Name -> loaded image registry standing for the reference's TextureManager (Texture.cpp:11-71).
-struct TextureRegistry {
-  FlatScene *out;
-  std::string root;
-  std::map<std::string, int> index;
-
-  void load(const std::string &name) {
-    if (name.empty() || index.count(name)) return;
-    std::string file = name;
-    const auto jpg = file.find(".jpg");  // only PPM can be read: tex.jpg -> tex.ppm
-    if (jpg != std::string::npos) file.replace(jpg, 4, ".ppm");
-    std::string path = root + "Textures/" + file;
-    if (!std::ifstream(path).good()) path = root + "../Textures/" + file;
-    Image img(path);
-    if (img.width == 0 || img.height == 0) {
-      std::cerr << "[ERROR] Failed to load texture (invalid dimensions) file=" << name << "\n";
-      return;
-    }
-    std::vector<uint16_t> px(static_cast<std::size_t>(img.width) * img.height * 3);
-    std::size_t k = 0;
-    for (const auto &row : img.pixels)
-      for (const auto &p : row)
-        for (int c = 0; c < 3; ++c) px[k++] = static_cast<uint16_t>(std::lround(p[c] * img.max_value));
-    index[name] = static_cast<int>(out->textures.size());
-    mirt_texture t;
-    std::memset(&t, 0, sizeof t);
-    t.width = img.width;
-    t.height = img.height;
-    t.max_value = img.max_value;
-    out->texels.push_back(std::move(px));
-    out->textures.push_back(t);
-    out->texture_names.push_back(name);
-  }
-  int find(const std::string &name) const {
-    if (name.empty()) return -1;
-    const auto it = index.find(name);
-    return it == index.end() ? -1 : it->second;
-  }
-};
-
-mirt_material flat_material(const Material &m, const TextureRegistry &reg) {
-  mirt_material o;
-  std::memset(&o, 0, sizeof o);
-  copy3(o.diffuse, m.diffuse_color);
-  copy3(o.specular, m.specular_color);
-  copy3(o.ambient, m.ambient_color);
-  copy3(o.emission, m.emission_color);
-  o.shininess = m.shininess;
-  o.glossiness = m.glossiness;
-  o.reflectivity = m.reflectivity;
-  o.transparency = m.transparency;
-  o.refractive_index = m.refractive_index;
-  o.emission_strength = m.emission_strength;
-  o.bump_strength = m.bump_strength;
-  o.has_texture = m.has_texture ? 1 : 0;
-  o.texture = reg.find(m.texture_file);
-  o.normal_map = reg.find(m.normal_map);
-  o.bump_map = reg.find(m.bump_map);
-  return o;
-}
-
-}  // namespace
-
-mirt_scene_desc FlatScene::desc() const {
-  mirt_scene_desc d;
-  std::memset(&d, 0, sizeof d);
-  d.n_nodes = static_cast<int32_t>(nodes.size());
-  d.n_leaf_prims = static_cast<int32_t>(leaf_prims.size());
-  d.n_prims = static_cast<int32_t>(prims.size());
-  d.n_plane_points = static_cast<int32_t>(plane_points.size() / 3);
-  d.n_materials = static_cast<int32_t>(materials.size());
-  d.n_lights = static_cast<int32_t>(lights.size());
-  d.n_textures = static_cast<int32_t>(textures.size());
-  d.nodes = nodes.data();
-  d.leaf_prims = leaf_prims.data();
-  d.prims = prims.data();
-  d.plane_points = plane_points.data();
-  d.materials = materials.data();
-  d.lights = lights.data();
-  d.textures = textures.data();
-  std::memcpy(d.background_color, background_color, sizeof background_color);
-  d.background_strength = background_strength;
-  return d;
-}
+#include "flatten_impl.h"
 
 FlatScene flatten_scene(const Scene &scene, const std::string &texture_root, bool build_tree) {
-  FlatScene fs;
-  std::string root = texture_root;
-  if (!root.empty() && root.back() != '/') root.push_back('/');
-
-  // textures first: only the maps named by spheres, cubes and planes are ever loaded
-  // (Raytracer.cpp:94-108); other shapes can use an image only if one of those loaded it
-  TextureRegistry reg{&fs, root, {}};
-  auto preload = [&reg](const Material &m) {
-    if (m.has_texture) reg.load(m.texture_file);
-    reg.load(m.normal_map);
-    reg.load(m.bump_map);
-  };
-  for (const auto &s : scene.spheres) preload(s.material);
-  for (const auto &s : scene.cubes) preload(s.material);
-  for (const auto &s : scene.planes) preload(s.material);
-  for (std::size_t i = 0; i < fs.textures.size(); ++i) fs.textures[i].rgb = fs.texels[i].data();
-
-  Builder b;
-  b.out = &fs;
-  const std::size_t total = scene.object_count();
-  fs.prims.reserve(total);
-  fs.materials.reserve(total);
-  b.boxes.reserve(total);
-  b.centres.reserve(total);
-  auto add = [&](const Shape &s, mirt_prim p, const BoundingBox &box, const Point &centre) {
-    fs.materials.push_back(flat_material(s.material, reg));
-    fs.prims.push_back(p);
-    b.boxes.push_back(box);
-    b.centres.push_back(centre);
-  };
-  const BoundingBox unit{Point(-1, -1, -1), Point(1, 1, 1)};
-  auto next_material = [&fs]() { return static_cast<int>(fs.materials.size()); };
-
-  for (const auto &s : scene.spheres)
-    add(s, base_prim(s, MIRT_SPHERE, next_material()), moving_or_static_box(s, unit), s.location);
-  for (const auto &s : scene.cubes) {
-    mirt_prim p = base_prim(s, MIRT_CUBE, next_material());
-    p.param[0] = s.scale.x; p.param[1] = s.scale.y; p.param[2] = s.scale.z;  // box UVs (Cube.cpp:106-131)
-    add(s, p, moving_or_static_box(s, unit), s.translation);
-  }
-  for (const auto &s : scene.planes) {
-    mirt_prim p = base_prim(s, MIRT_PLANE, next_material());
-    p.first_point = static_cast<int32_t>(fs.plane_points.size() / 3);
-    p.n_points = static_cast<int32_t>(s.points.size());
-    BoundingBox pb{Point(0, 0, 0), Point(0, 0, 0)};
-    Point centre(0, 0, 0);
-    for (std::size_t i = 0; i < s.points.size(); ++i) {
-      const Point &q = s.points[i];
-      fs.plane_points.insert(fs.plane_points.end(), {q.x, q.y, q.z});
-      if (i == 0) pb = BoundingBox{q, q};
-      else pb.grow(BoundingBox{q, q});
-      centre = centre + q;
-    }
-    if (!s.points.empty()) centre = centre * (1.0 / s.points.size());
-    // an empty plane keeps the degenerate box at the origin un-transformed (Plane.cpp:136-138)
-    add(s, p, s.points.empty() ? pb : moving_or_static_box(s, pb), centre);
-  }
-  for (const auto &s : scene.toruses) {
-    mirt_prim p = base_prim(s, MIRT_TORUS, next_material());
-    p.param[0] = s.major_radius; p.param[1] = s.minor_radius;
-    const double R = s.major_radius + s.minor_radius, r = s.minor_radius;
-    add(s, p, moving_or_static_box(s, BoundingBox{Point(-R, -R, -r), Point(R, R, r)}), s.location);
-  }
-  for (const auto &s : scene.cylinders) {
-    mirt_prim p = base_prim(s, MIRT_CYLINDER, next_material());
-    p.param[0] = s.radius; p.param[1] = s.depth;
-    const double r = s.radius, h = s.depth / 2.0;
-    add(s, p, moving_or_static_box(s, BoundingBox{Point(-r, -r, -h), Point(r, r, h)}), s.location);
-  }
-  for (const auto &s : scene.cones) {
-    mirt_prim p = base_prim(s, MIRT_CONE, next_material());
-    p.param[0] = s.radius; p.param[1] = s.depth;
-    const double r = s.radius, h = s.depth / 2.0;
-    add(s, p, moving_or_static_box(s, BoundingBox{Point(-r, -r, -h), Point(r, r, h)}), s.location);
-  }
-
-  if (build_tree) {
-    b.order.resize(total);
-    for (std::size_t i = 0; i < total; ++i) b.order[i] = static_cast<int32_t>(i);
-    b.run();  // an empty scene still gets its one empty leaf
-    fs.leaf_prims = std::move(b.order);
-  }
-
-  for (const auto &l : scene.lights) {
-    mirt_light o;
-    std::memset(&o, 0, sizeof o);
-    copy3(o.location, l.location);
-    copy3(o.color, l.color);
-    copy3(o.normal, l.normal);
-    o.intensity = l.intensity;
-    o.area_size[0] = l.area_size_x;
-    o.area_size[1] = l.area_size_y;
-    o.type = l.light_type == "AREA" ? MIRT_LIGHT_AREA : MIRT_LIGHT_POINT;
-    o.area_shape = (l.area_shape == "SQUARE" || l.area_shape == "RECTANGLE") ? MIRT_AREA_RECT : MIRT_AREA_DISK;
-    o.samples = l.samples;
-    fs.lights.push_back(o);
-  }
-  copy3(fs.background_color, scene.settings.background_color);
-  fs.background_strength = scene.settings.background_strength;
-  return fs;
+  return mirt_flatten::scene<Image>(scene, texture_root, build_tree);
 }
 
-mirt_camera flatten_camera(const Camera &c) {
-  mirt_camera o;
-  std::memset(&o, 0, sizeof o);
-  copy3(o.location, c.location);
-  copy3(o.gaze, c.gaze_direction);
-  copy3(o.up, c.up_direction);
-  o.focal_length = c.focal_length;
-  o.sensor_height = c.sensor_height;
-  o.focus_distance = c.focus_distance;
-  o.aperture_fstop = c.aperture_fstop;
-  o.dof_enabled = c.dof_enabled ? 1 : 0;
-  return o;
-}
+mirt_camera flatten_camera(const Camera &c) { return mirt_flatten::camera(c); }
 
-mirt_config flatten_config(const RenderConfig &c) {
-  mirt_config o;
-  std::memset(&o, 0, sizeof o);
-  o.max_ray_depth = c.max_ray_depth;
-  o.shadow_samples = c.shadow_samples;
-  o.glossy_samples = c.glossy_samples;
-  o.enable_motion_blur = c.enable_motion_blur ? 1 : 0;
-  o.enable_textures = c.enable_textures ? 1 : 0;
-  o.use_adaptive_epsilon = c.use_adaptive_epsilon ? 1 : 0;
-  o.tone_mapping_mode = c.tone_mapping_mode == "reinhard" ? MIRT_TONEMAP_REINHARD
-                        : c.tone_mapping_mode == "exposure" ? MIRT_TONEMAP_EXPOSURE
-                                                             : MIRT_TONEMAP_NONE;
-  o.enable_gamma_correction = c.enable_gamma_correction ? 1 : 0;
-  o.light_intensity_factor = c.light_intensity_factor;
-  o.ambient_factor = c.ambient_factor;
-  o.ray_offset_epsilon = c.ray_offset_epsilon;
-  o.adaptive_epsilon_scale = c.adaptive_epsilon_scale;
-  o.pure_glass_threshold = c.pure_glass_threshold;
-  o.exposure = c.exposure;
-  o.gamma = c.gamma;
-  o.seed = c.seed;
-  o.sampling = MIRT_SAMPLING_JITTER;
-  return o;
-}
+mirt_config flatten_config(const RenderConfig &c) { return mirt_flatten::config(c); }
