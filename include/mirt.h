@@ -222,8 +222,10 @@ void mirt_scene_destroy(mirt_scene *scene);
 enum { MIRT_BUILDER_HOST = 0, MIRT_BUILDER_DEVICE = 1 };
 typedef struct mirt_build_options {
   int32_t builder;    /* MIRT_BUILDER_* */
-  int32_t leaf_size;  /* DEVICE: most primitives of a leaf, 1 .. 4 (the reference: MAX_LEAF_SIZE 2, Bvh.h:12); 0: default
-                         (1: a primitive test costs many box tests, measured fastest on a million primitives) */
+  int32_t leaf_size;  /* DEVICE: most primitives of a leaf, 1 .. 4; 0: default = 2, the reference's MAX_LEAF_SIZE (Bvh.h:12).
+                         1 is faster on a million primitives (356 against 334 Mrays/s: fewer primitive tests), but
+                         a ray then meets fewer of the far, tiny tori whose quartic the reference itself cannot
+                         resolve, and frames of such scenes move from 65 to 51 dB against the reference's */
   int32_t reserved[6];
 } mirt_build_options;
 /* mirt_scene_create with a choice of builder; options == NULL is mirt_scene_create. */
@@ -315,8 +317,9 @@ int mirt_render_tiles_begin(mirt_scene *scene, const mirt_camera *camera, const 
                             double *d_rgb_out, void *stream, int slot);
 int mirt_render_tiles_end(mirt_scene *scene, int slot, mirt_stats *stats);
 
-/* mirt_render_tiles for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+/* mirt_render_tiles for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc, code that must not disturb an allocator).  The call still waits for the frame and reads its
+ * counters back, so it is not for use under HIP graph capture.  No counterpart in the reference.  Same arguments, same
  * frame, same statistics -- but the call allocates nothing, on the device or on the host: its working
  * memory (control block, pixel accumulator, shadow queue, two ray queues) is a carve-up of one static
  * array of mirt_noalloc_scratch_bytes() = 64 MiB that each GPU the library runs on holds until the
@@ -341,7 +344,8 @@ uint64_t mirt_noalloc_scratch_bytes(void);
  * band_ms[0 .. min(bands, max_bands)) with the time, in milliseconds since the frame's first block
  * started, at which the last primary sample of band b (pixel rows 16b .. 16b+15) was shaded -- shadow
  * and secondary rays of the band may still be in flight then.  Bands this rank owns no tile of read 0.
- * mirt_render_tiles_noalloc leaves the feed out. */
+ * The feed is one buffer per scene: record with one frame in flight (frames that overlap mix their
+ * marks).  mirt_render_tiles_noalloc leaves the feed out. */
 int mirt_scene_record_progress(mirt_scene *scene, int enable);
 int mirt_scene_progress(mirt_scene *scene, double *band_ms, int max_bands);
 

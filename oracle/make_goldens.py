@@ -20,6 +20,9 @@ OUT = os.path.join(ROOT, "tests", "golden")
 # the reference's eight scenes, Test7 with a glass sphere added (the 64-spp depth-of-field configuration) and a
 # hand-written scene whose sphere, cube and plane carry normal maps (no bundled scene has one)
 SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene", "Test7_glass", "NormalMap"]
+# Test4 with 600 small spheres added (oracle/make_ties_scene.py): coincident surfaces in a scene large enough
+# for the engine's large-scene walk; hits and colours only
+TIES = ["Test4_ties"]
 W, H = 96, 54  # deterministic (pixel-centre) maps
 SYNTHETIC = [("synthetic100k", 100000, 0x5EED)]  # generated scenes (raytracer_amd/host/synthetic.h): a deep BVH
 
@@ -72,9 +75,9 @@ def main():
         os.makedirs(os.path.join(tmp, "ASCII"))
         for name, count, seed in SYNTHETIC:
             HostScene.synthetic(count, seed).write_ascii(os.path.join(tmp, "ASCII", f"{name}.txt"))
-        for s in SCENES + [name for name, _, _ in SYNTHETIC]:
+        for s in SCENES + TIES + [name for name, _, _ in SYNTHETIC]:
             scene = f"ASCII/{s}.txt"
-            root = FIX if s in SCENES else tmp
+            root = FIX if s in SCENES + TIES else tmp
             if s in SCENES:
                 dumps[f"{s}_scene"] = np.frombuffer(harness("dump-scene", scene)[0], dtype=np.uint8)
                 dumps[f"{s}_bvh"] = np.frombuffer(harness("dump-bvh", scene)[0], dtype=np.uint8)

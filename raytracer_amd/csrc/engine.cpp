@@ -848,7 +848,7 @@ int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_optio
     HIP_TRY(upload(sc->leaf_tagged, std::vector<int32_t>()));
     sc->bvh_depth = 0;
     sc->dbvh.reset(new DeviceBvh);
-    const uint32_t leaf = opts.leaf_size ? (uint32_t)opts.leaf_size : (uint32_t)env_size("MIRT_DEVICE_LEAF", 1);
+    const uint32_t leaf = opts.leaf_size ? (uint32_t)opts.leaf_size : (uint32_t)env_size("MIRT_DEVICE_LEAF", 2);
     const int be = sc->dbvh->build(sc->stream, sc->prims.as<DPrim>(), sc->motion_ends.as<double>(),
                                    sc->transparency.as<double>(), (uint32_t)s.n_prims, leaf);
     if (be != 0)

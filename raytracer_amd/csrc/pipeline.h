@@ -879,6 +879,7 @@ DEV void progress_mark(const TraceArgs &a, uint32_t vb, bool finished) {
   int gx, gy;
   uint32_t px;
   block_pixel(a.fr, block, 0, gx, gy, px);
+  if (gy >= a.fr.height) return;  // a block wholly below the image (an edge tile's padding) has no row band
   const unsigned long long now = wall_clock64();
   if (finished) atomicMax(a.progress + 1 + gy / 16, now);
   else atomicMin(a.progress, now);

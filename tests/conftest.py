@@ -16,6 +16,9 @@ FIXTURES = os.path.join(ROOT, "fixtures")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the reference's eight scenes, Test7 with a glass sphere added, and a hand-written scene with normal maps
 SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_scene", "Test7_glass", "NormalMap"]
+# Test4 plus 600 small spheres (oracle/make_ties_scene.py): coincident surfaces in a scene above the 512
+# primitives at which the engine chooses its large-scene walk; hits and depth-5 colours from the reference
+TIES = ["Test4_ties"]
 # generated scenes (raytracer_amd/host/synthetic.h): name -> (primitives, seed); oracle/make_goldens.py
 # feeds the same scenes to the reference as ASCII files
 SYNTHETIC = {"synthetic100k": (100000, 0x5EED)}

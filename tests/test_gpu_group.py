@@ -37,6 +37,25 @@ def test_group_frame_equals_single_gpu_frame(members, host_scenes, device_scenes
     grp.close()
 
 
+def test_group_over_two_devices_uses_rccl(host_scenes, device_scenes):
+    """The gather between distinct devices (ncclSend / ncclRecv over xGMI); needs a second GPU."""
+    from raytracer_amd import _abi as A
+    if A.engine_lib().mirt_device_count() < 2:
+        pytest.skip("one GPU: the RCCL gather between devices cannot run here (it has never run: parity unpinned on more than one device)")
+    hs, ds = host_scenes("Test5"), device_scenes("Test5")
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=5, glossy_samples=2)
+    want, st = ds.render(cam, cfg, 200, 117, 2)
+    grp = DeviceGroup(hs, [0, 1])
+    assert grp.transport.startswith("RCCL")
+    for _ in range(2):
+        got, total, per = grp.render(cam, cfg, 200, 117, 2)
+        assert np.abs(got - want).max() <= 1e-12
+        for k in COUNTERS:
+            assert total[k] == st[k], k
+    grp.close()
+
+
 def test_group_on_a_large_scene_and_bad_arguments(host_scenes):
     from raytracer_amd import HostScene, DeviceScene, MirtError
     hs = HostScene.synthetic(20000)

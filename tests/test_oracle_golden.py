@@ -7,12 +7,12 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from conftest import GOLDEN, SCENES, SYNTHETIC
+from conftest import GOLDEN, SCENES, SYNTHETIC, TIES
 from golden_cases import REAL_CASES, RENDER_CASES
 from raytracer_amd import default_config
 
 
-@pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
+@pytest.mark.parametrize("name", SCENES + TIES + sorted(SYNTHETIC))
 def test_closest_hit_bit_exact(name, host_scenes):
     hs = host_scenes(name)
     gold = np.load(os.path.join(GOLDEN, f"hits_{name}.npz"))
@@ -25,7 +25,7 @@ def test_closest_hit_bit_exact(name, host_scenes):
         assert np.array_equal(got[k], gold[k]), k
 
 
-@pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
+@pytest.mark.parametrize("name", SCENES + TIES + sorted(SYNTHETIC))
 def test_trace_rgb_bit_exact(name, host_scenes):
     """Raytracer::trace of pixel-centre rays at depth 5, motion blur off (sequential draws feed the
     area-light strata of Test6/Test7)."""

@@ -26,7 +26,11 @@ def test_noalloc_entry_point_matches_render_tiles(host_scenes, device_scenes):
         want = torch.empty(w * h * 3, dtype=torch.float64, device=dev)
         got = torch.full((w * h * 3,), -7.0, dtype=torch.float64, device=dev)
         st_want = ds.render_tiles(cam, cfg, w, h, spp, w, h, 0, 1, want.data_ptr())
+        ds.render_tiles_noalloc(cam, cfg, w, h, spp, w, h, 0, 1, got.data_ptr())  # (the first call uploads the light table)
+        torch.cuda.synchronize(dev)
+        free_before = torch.cuda.mem_get_info(dev)[0]
         st_got = ds.render_tiles_noalloc(cam, cfg, w, h, spp, w, h, 0, 1, got.data_ptr())
+        assert torch.cuda.mem_get_info(dev)[0] == free_before  # the call took no device memory
         err = float((got - want).abs().max())
         print(f"{w}x{h}x{spp}: max abs diff {err:.3e}, launches {st_want['launches']} vs {st_got['launches']}")
         assert err <= 1e-12
