@@ -218,7 +218,7 @@ void mirt_scene_destroy(mirt_scene *scene);
  * form of the WIDE traversal -- the only traversal such a scene has.  The closest hit of a ray does not
  * depend on the tree except where the reference's own rules make it: a box of zero thickness is never
  * hit (BoundingBox.h:27), so a scene with planes is refused (MIRT_ERR_UNSUPPORTED), and hits at exactly
- * equal distances may be won by the other surface (Bvh.cpp:312-332), as with WIDE on a host tree. */
+ * equal distances may be won by the other surface (Bvh.cpp:312-332): there is no reference order to restore. */
 enum { MIRT_BUILDER_HOST = 0, MIRT_BUILDER_DEVICE = 1 };
 typedef struct mirt_build_options {
   int32_t builder;    /* MIRT_BUILDER_* */
@@ -355,9 +355,11 @@ int mirt_scene_progress(mirt_scene *scene, double *band_ms, int max_bands);
  * ORDERED (per ray, nearer child first, farther child on a per-lane stack) tests fewer boxes; it
  * returns the same closest hit except that two surfaces at exactly the same distance may swap.
  * WIDE walks the same tree collapsed into 4-wide nodes, nearer child first like ORDERED, and runs the primitive
- * tests a kind at a time across the wave: the walk for large scenes (same closest hit, exact ties may swap).
- * AUTO: PACKET up to 512 primitives, WIDE above -- so by default a large scene trades the reference's order
- * among hits at exactly equal distances for speed; LANE (or MIRT_TRAVERSAL=lane in the environment) restores it. */
+ * tests a kind at a time across the wave: the walk for large scenes.  Same closest hit; a closest-hit ray that
+ * meets two surfaces within a relative 1e-9 of one distance (MIRT_TIE_BAND in the environment; 0: off) is walked
+ * again as LANE walks, so coincident surfaces resolve as in the reference whenever the scene carries the
+ * reference's tree (MIRT_BUILDER_HOST); a tree built on the device has no reference order to restore.
+ * AUTO: PACKET up to 512 primitives, WIDE above. */
 enum { MIRT_TRAVERSAL_AUTO = 0, MIRT_TRAVERSAL_PACKET = 1, MIRT_TRAVERSAL_LANE = 2, MIRT_TRAVERSAL_ORDERED = 3,
        MIRT_TRAVERSAL_WIDE = 4 };
 int mirt_scene_set_traversal(mirt_scene *scene, int mode);

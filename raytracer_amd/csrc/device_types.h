@@ -128,6 +128,11 @@ struct DScene {
   // walk may stop at the first opaque hit it finds instead of chaining closest hits
   int32_t shadow_any_hit;
   int32_t pad_;
+  // The wide walk's guard against surfaces that coincide (see wide_step): tie_hi = 1 + band widens the distance
+  // a primitive is tested against, tie_lo = (1 - band) / (1 + band) marks a hit that lands within the band of the
+  // one it replaces; such rays are walked again in the reference's order.  Both 1: no band (no binary tree to
+  // walk again, or switched off).
+  double tie_hi, tie_lo;
 };
 
 // Camera with the basis of Camera::get_ray (Camera.cpp:32-58) evaluated once on the host.

@@ -930,6 +930,16 @@ int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_optio
     const char *ah = std::getenv("MIRT_SHADOW_ANY_HIT");  // "0": chain closest hits even where any-hit is exact
     d.shadow_any_hit = (any_hit && !(ah && ah[0] == '0')) ? 1 : 0;
   }
+  {
+    // Two surfaces at (nearly) one distance -- a cylinder standing on a plane -- go to whichever the reference
+    // tests later and accepts (Bvh.cpp:312-332 with each intersector's own comparison): the wide walk flags rays
+    // whose two best hits lie within this relative band and walks them again over the reference's tree in the
+    // reference's order.  Needs that tree; MIRT_TIE_BAND=0 switches it off.
+    const char *tb = std::getenv("MIRT_TIE_BAND");
+    const double band = !device_tree ? (tb && *tb ? std::atof(tb) : 1e-9) : 0.0;
+    d.tie_hi = 1.0 + band;
+    d.tie_lo = (1.0 - band) / (1.0 + band);
+  }
 
   guard.s = nullptr;
   *out = sc;

@@ -366,8 +366,11 @@ DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double
 //    walks on; when too few lanes can still walk, the wave picks the kind most lanes hold and every
 //    lane holding one tests one primitive of that kind -- one intersector, many lanes.
 // A primitive is tested against the closest hit known when its turn comes, so the closest hit is the
-// same as in the other walks; the order of the tests differs (exact ties may resolve differently, as
-// in the ordered walk), and boxes are tested against a closest hit that may be a little out of date.
+// same as in the other walks; boxes are tested against a closest hit that may be a little out of date.
+// The order of the tests differs, which matters where two surfaces coincide (each intersector accepts on
+// its own object-space distance and records the world-space one, so the later test can win by a rounding):
+// closest-hit rays whose two best hits lie within the scene's tie band of each other are walked again
+// in the reference's order (walk_again_in_order) when the scene has the reference's tree.
 #ifndef PEND_SLOTS
 #define PEND_SLOTS 8  // primitives a lane can hold untested (at most 8: one byte of slot mask per kind)
 #endif
@@ -378,6 +381,8 @@ DEV void traverse_ordered(const DScene &sc, const RayL &ray, bool active, double
 #define WIDE_DRAIN_MIN 24  // test a batch as soon as this many lanes hold a primitive of one kind
 #endif
 
+#define WIDE_TIE 0x100u  // WideWalk::up: two hits of this ray lay within the scene's tie band of each other
+
 // A lane's place in the wide walk.  The walk is written as one wave step at a time (wide_step) so that
 // a kernel can interleave steps with handing finished lanes their next ray.
 struct WideWalk {
@@ -385,7 +390,8 @@ struct WideWalk {
   int32_t cur;            // >= 0: wide node; < 0: ~leaf; WIDE_NONE: nothing left to visit
   uint32_t used;          // bit s: slot s of this lane's list holds a primitive
   unsigned long long km;  // bits [8k, 8k + 8): the slots that hold a primitive of kind k
-  uint32_t up;            // the sign of the ray direction per axis, as the ordered walk reads it
+  uint32_t up;            // bits 0-2: the sign of the ray direction per axis, as the ordered walk reads it; WIDE_TIE
+  DEV bool tied() const { return (up & WIDE_TIE) != 0; }
   DEV void start(const RayL &ray, bool active) {
     sp = 0;
     cur = active ? 0 : WIDE_NONE;
@@ -422,6 +428,26 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
   auto pop = [&]() {
     w.sp--;
     return w.sp < WIDE_STACK_LDS ? stack_lds[w.sp][tid] : deep[w.sp - WIDE_STACK_LDS];
+  };
+  // One primitive against this lane's ray.  Closest-hit walks keep closest_t a little beyond the closest hit
+  // (by the scene's tie band, DScene::tie_hi): a surface that coincides with the closest one is then still
+  // reached -- through its boxes and in its intersector -- whichever of the two the walk meets first, and
+  // the lane is marked; its ray is walked again in the reference's order when this walk is over
+  // (walk_again_in_order).  The old bound waits in LDS while the intersector runs, not in registers.
+  __shared__ double bound_was[256];
+  auto test = [&](int pi) {
+    n_prim++;
+    if (SHADOW) {
+      isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+      return;
+    }
+    *(volatile double *)&bound_was[tid] = closest_t;
+    isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+    const double was = *(volatile double *)&bound_was[tid];
+    if (closest_t != was) {  // hit: closest_t is the new distance
+      if (closest_t >= was * sc.tie_lo) w.up |= WIDE_TIE;
+      closest_t *= sc.tie_hi;
+    }
   };
   const int room = PEND_SLOTS - __popc(w.used);
   const bool walks = w.cur != WIDE_NONE && room >= 2;
@@ -500,9 +526,7 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
             for (int k = 0; k < n; k++) {
               const int tag = indirect ? rdonly(sc.leaf_tagged)[lp.x + k] : lprim(k);
               if (tag >= 0 && !(ANYHIT && (tag & LEAF_CLEAR_BIT))) {
-                const int pi = tag & LEAF_PRIM_MASK;
-                n_prim++;
-                isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+                test(tag & LEAF_PRIM_MASK);
               }
             }
           }
@@ -520,20 +544,48 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
     const int pi = pend[slot][tid];
     w.used &= ~(1u << slot);
     w.km &= ~((1ull << slot) << (8 * kind));
-    n_prim++;
-    isect_prim_lane<SHADOW, UV, MOTION>(sc, sc.prims + pi, pi, ray, t_min, closest_t, best);
+    test(pi);
     if (ANYHIT && best.prim >= 0 && best.t < any_limit) w.stop();
   }
   return true;
+}
+
+// The rays of the wave whose wide walk met two surfaces within the tie band (`again`; rare: coincident
+// surfaces) are walked once more through the binary tree in the reference's own order (traverse_lane), from
+// the start: which of the two surfaces wins is then decided as Bvh.cpp:312-332 decides it.  Wave-uniform call.
+template <bool UV, bool MOTION>
+DEV void walk_again_in_order(const DScene &sc, const RayL &ray, bool again, double t_min, double t_max, Best<UV> &best,
+                             unsigned &n_node, unsigned &n_prim) {
+  double closest = t_max;
+  if (again) {
+    best.prim = -1;
+    best.t = 0;
+  }
+  traverse_lane<false, UV, MOTION>(sc, ray, again, t_min, closest, best, n_node, n_prim);
 }
 
 template <bool SHADOW, bool UV, bool MOTION>
 DEV void traverse_wide(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
                        Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
   WideWalk w;
-  int32_t deep[WIDE_STACK_DEEP];  // private memory; touched only by lanes whose stack outgrows LDS
+  // private memory; touched only by lanes whose stack outgrows LDS (the last two words: the distance limit
+  // the walk was called with, kept for walk_again_in_order without holding registers)
+  int32_t deep[WIDE_STACK_DEEP + 2];
+  if (!SHADOW) {
+    const unsigned long long bits = __double_as_longlong(closest_t);
+    *(volatile int32_t *)&deep[WIDE_STACK_DEEP] = (int32_t)(bits & 0xffffffffull);
+    *(volatile int32_t *)&deep[WIDE_STACK_DEEP + 1] = (int32_t)(bits >> 32);
+  }
   w.start(ray, active);
   while (wide_step<SHADOW, UV, MOTION>(sc, ray, t_min, closest_t, best, w, deep, n_node, n_prim)) {
+  }
+  if (!SHADOW) {
+    if (__any(w.tied())) {
+      const unsigned long long bits = (unsigned long long)(uint32_t)*(volatile int32_t *)&deep[WIDE_STACK_DEEP] |
+                                      ((unsigned long long)(uint32_t)*(volatile int32_t *)&deep[WIDE_STACK_DEEP + 1] << 32);
+      walk_again_in_order<UV, MOTION>(sc, ray, w.tied(), t_min, __longlong_as_double((long long)bits), best, n_node, n_prim);
+    }
+    if (best.prim >= 0) closest_t = best.t;  // (the walk kept it a tie band beyond)
   }
 }
 
@@ -1374,7 +1426,10 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_cl
   int32_t deep[WIDE_STACK_DEEP];
   w.start(ray, false);
   for (;;) {
-    if (has_ray && !w.busy()) {  // found (or nothing to find): the hit goes out, the lane is free
+    const bool found = has_ray && !w.busy();  // (or nothing to find)
+    if (__any(found && w.tied()))
+      walk_again_in_order<UV, MOTION>(sc, ray, found && w.tied(), 1e-5, 1.7976931348623157e308, best, n_node, n_prim);
+    if (found) {  // the hit goes out, the lane is free
       hit_store<UV>(a.hits, a.hits_uv, mine, best);
       has_ray = false;
     }

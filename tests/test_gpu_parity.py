@@ -52,12 +52,12 @@ def test_closest_hit_vs_golden_and_oracle(name, traversal, host_scenes, device_s
 @pytest.mark.parametrize("name", SCENES + sorted(SYNTHETIC))
 def test_deterministic_render_vs_golden(name, traversal, host_scenes, device_scenes):
     """Pixel-centre, time 0.5, depth 5 trace() colours against the reference's own values."""
-    if traversal in ("ordered", "wide") and name in ("Test4", "Test6"):
+    if traversal == "ordered" and name in ("Test4", "Test6"):
         # these two scenes have coincident surfaces (a glass cylinder standing on the ground plane, ...):
-        # which of two hits at exactly the same distance wins depends on the order of the tests, and
-        # the walks that visit the nearer child first (never chosen automatically for scenes this
-        # small) do not keep the reference's order
-        pytest.skip("exact ties are order dependent")
+        # which of two hits at the same distance wins depends on the order of the tests, and the binary
+        # walk that visits the nearer child first (opt-in only) does not keep the reference's order; the
+        # wide walk does not either, but walks such rays again in that order
+        pytest.skip("ties are order dependent")
     hs, ds = host_scenes(name), device_scenes(name, traversal)
     cam, _ = hs.camera(0)
     cfg = default_config(max_ray_depth=5, enable_motion_blur=0, sampling=1, enable_gamma_correction=0)
@@ -501,11 +501,13 @@ def test_million_primitive_cloud_at_4k(million):
 
 
 def test_exact_ties_under_the_large_scene_walk(host_scenes, device_scenes):
-    """Above 512 primitives the engine picks the wide walk by itself, which visits nearer children first and
-    so may give an exact tie -- two surfaces at the same distance, e.g. the glass cylinder standing on the
-    ground plane (Cylinder.cpp:40, Plane.cpp:32, Bvh.cpp:312-332) -- to the other surface than the reference
-    does.  Measured here on Test4 with 600 spheres added (two thirds of them resting on the plane): how many
-    pixels that costs, against the reference's own hits and colours, next to the walk that keeps its order."""
+    """Above 512 primitives the engine picks the wide walk by itself, which visits nearer children first.  Where
+    two surfaces lie at one distance -- the glass cylinder standing on the ground plane of Test4 -- the reference
+    gives the hit to whichever it tests later and accepts (Cylinder.cpp:40, Plane.cpp:32, Bvh.cpp:312-332), so a
+    walk in another order may give it to the other: 37 of 5184 pixels of this scene (Test4 with 600 spheres added,
+    two thirds of them resting on the plane), 29.8 dB, before the wide walk learnt to notice such rays and walk
+    them again in the reference's order.  Now: the reference's own hits and colours, from either walk; the
+    nearer-first binary walk, which has no such guard, shows what the guard is worth."""
     name = "Test4_ties"
     hs = host_scenes(name)
     assert hs.desc.n_prims > 512
@@ -514,7 +516,7 @@ def test_exact_ties_under_the_large_scene_walk(host_scenes, device_scenes):
     cfg = default_config(max_ray_depth=5, enable_motion_blur=0, sampling=1, enable_gamma_correction=0)
     want = gold["trace_rgb_depth5"].reshape(H, W, 3)
     result = {}
-    for walk in ("lane", "auto"):
+    for walk in ("lane", "auto", "ordered"):
         ds = device_scenes(name, walk)
         got = ds.trace_ids(cam, W, H)
         frame, _ = ds.render(cam, cfg, W, H, 1)
@@ -524,14 +526,10 @@ def test_exact_ties_under_the_large_scene_walk(host_scenes, device_scenes):
         print(f"{name} {walk} (walk {ds.info()['traversal']}): {ids_off} of {W * H} primary hits and {px_off} pixels of the "
               f"depth-5 frame differ from the reference's, PSNR {result[walk][2]:.1f} dB")
     assert device_scenes(name, "auto").info()["traversal"] == 4  # the wide walk
-    # the reference's order: everything equal
-    assert result["lane"][0] == 0 and result["lane"][2] >= 80.0
-    # the wide walk: primary hits are not ties (the camera sees no coincident surfaces edge-on); deeper rays
-    # -- refracted through the cylinder's base, reflected off the plane under a sphere -- are, a handful of pixels
-    assert result["auto"][0] <= 2
-    assert result["auto"][1] <= 0.02 * W * H and result["auto"][2] >= 25.0
-    differ = int((np.abs(result["auto"][3] - result["lane"][3]).max(axis=2) > 1e-9).sum())
-    print(f"{name}: {differ} pixels differ between the two walks")
+    for walk in ("lane", "auto"):  # (the 35 pixels: the last digits of sums taken in another order)
+        assert result[walk][0] == 0 and result[walk][2] >= 150.0
+    assert np.abs(result["auto"][3] - result["lane"][3]).max() <= 1e-12
+    assert result["ordered"][1] > result["auto"][1]  # the scene does hold ties that an unguarded walk gets wrong
 
 
 def test_cli_renders_the_plumbing_configuration(host_scenes, device_scenes, tmp_path):
