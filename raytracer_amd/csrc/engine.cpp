@@ -1351,7 +1351,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
         sa.grab = a.shadow_count + 1;  // a spare word of the launch's tail block, zeroed with it
         launch_shadow_stream(sc->d.shadow_any_hit != 0, sc->resident_grid, stream, sa);
       } else {
-        launch_shadow(sc->walk, sc->any_strata, consumer_grid, stream, sa);
+        launch_shadow(sc->walk, sc->any_strata, sc->d.shadow_any_hit != 0, consumer_grid, stream, sa);
       }
       HIP_TRY(hipGetLastError());
       if (kernel_timing) {

@@ -211,9 +211,11 @@ DEV bool box_hit_early(const double *lo, const double *hi, const RayL &r, double
 
 // intersect_bvh (Bvh.cpp:306-333) for the 64 rays of a wave at once.  Must be called by all lanes
 // of the wave; `active` masks the lanes that have a ray.
-template <bool SHADOW, bool UV, bool MOTION>
+// ANYHIT (shadow segments of a scene whose primitives are all opaque or perfectly clear): clear primitives
+// are not tested, and a lane that has found a hit nearer than `any_limit` takes no further part.
+template <bool SHADOW, bool UV, bool MOTION, bool ANYHIT = false>
 DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double t_min, double &closest_t,
-                         Best<UV> &best, unsigned &n_node, unsigned &n_prim) {
+                         Best<UV> &best, unsigned &n_node, unsigned &n_prim, double any_limit = 0.0) {
   const int n_nodes = sc.n_nodes;
   int resume = active ? 0 : 0x7fffffff;  // first node at which this lane takes part again
   int node = 0;
@@ -237,10 +239,21 @@ DEV void traverse_packet(const DScene &sc, const RayL &ray, bool active, double 
     }
     if (nd.first >= 0) {
       for (int k = 0; k < nd.count; k++) {
-        const int pi = rdonly(sc.leaf_prims)[nd.first + k];
+        int pi;
+        if (ANYHIT) {
+          const int tag = rdonly(sc.leaf_tagged)[nd.first + k];
+          if (tag & LEAF_CLEAR_BIT) continue;
+          pi = tag & LEAF_PRIM_MASK;
+        } else {
+          pi = rdonly(sc.leaf_prims)[nd.first + k];
+        }
         if (hit) {
           n_prim++;
           isect_prim<SHADOW, UV, MOTION>(sc, rdonly(sc.prims) + pi, pi, ray, t_min, closest_t, best);
+          if (ANYHIT && best.prim >= 0 && best.t < any_limit) {
+            hit = false;
+            resume = 0x7fffffff;
+          }
         }
       }
       node = nd.skip;
@@ -1506,7 +1519,7 @@ __global__ __launch_bounds__(256) void k_shade(const TraceArgs a) {
 // parked in LDS and the parts of the work item that are only needed later (colour, pixel, random
 // key, light) stay in memory: the traversal with its inlined intersectors sets the kernel's vector
 // register peak, and every register freed there counts towards one more resident wave per SIMD.
-template <int WALK>
+template <int WALK, bool ANYHIT>
 DEV void shadow_block_items(const ShadowArgs &a, const LightTable &lights, bool valid, size_t slot, unsigned &n_node,
                       unsigned &n_prim, unsigned &n_seg) {
   // per lane: the item (point, colour, key, pixel, light) and the walk state
@@ -1578,7 +1591,10 @@ DEV void shadow_block_items(const ShadowArgs &a, const LightTable &lights, bool 
 #if MIRT_PROFILE == 2
     PROF_MARK(2);
 #endif
-    traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+    if constexpr (ANYHIT && WALK == WALK_PACKET)
+      traverse_packet<true, false, false, true>(sc, ray, busy, eps, closest, best, n_node, n_prim, dist - cur);
+    else
+      traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
 #if MIRT_PROFILE == 2
     PROF_MARK(1);
 #endif
@@ -1638,7 +1654,7 @@ DEV void shadow_block_items(const ShadowArgs &a, const LightTable &lights, bool 
 // parked in LDS and the item (point, colour, pixel, random key, light) stays there throughout: the
 // traversal with its inlined intersectors sets the kernel's vector register peak, and every register
 // freed there counts towards one more resident wave per SIMD.
-template <int WALK>
+template <int WALK, bool ANYHIT>
 DEV void shadow_block_strata(const ShadowArgs &a, const LightTable &lights, bool valid, size_t slot, unsigned &n_node,
                       unsigned &n_prim, unsigned &n_seg) {
   // per item (indexed by the lane that loaded it)
@@ -1759,7 +1775,10 @@ DEV void shadow_block_strata(const ShadowArgs &a, const LightTable &lights, bool
 #if MIRT_PROFILE == 2
     PROF_MARK(2);
 #endif
-    traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+    if constexpr (ANYHIT && WALK == WALK_PACKET)
+      traverse_packet<true, false, false, true>(sc, ray, busy, eps, closest, best, n_node, n_prim, dist - cur);
+    else
+      traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
 #if MIRT_PROFILE == 2
     PROF_MARK(1);
 #endif
@@ -1796,7 +1815,8 @@ DEV void shadow_block_strata(const ShadowArgs &a, const LightTable &lights, bool
 
 // Fixed-size grid striding over the virtual blocks of the shadow queue.
 // STRATA: some light of the frame has more than one stratum.
-template <int WALK, bool STRATA>
+// ANYHIT (packet walk only): see traverse_packet; a stratum is then one segment, never a chain.
+template <int WALK, bool STRATA, bool ANYHIT = false>
 __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
   __shared__ LightTable lights;
@@ -1805,8 +1825,8 @@ __global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_SHADOW_WAVES) void k
   for (uint32_t vb = blockIdx.x; vb < v.total; vb += gridDim.x) {
     size_t slot;
     const bool valid = view_entry(v, vb, a.shard_cap, slot);
-    if (STRATA) shadow_block_strata<WALK>(a, lights, valid, slot, n_node, n_prim, n_seg);
-    else shadow_block_items<WALK>(a, lights, valid, slot, n_node, n_prim, n_seg);
+    if (STRATA) shadow_block_strata<WALK, ANYHIT>(a, lights, valid, slot, n_node, n_prim, n_seg);
+    else shadow_block_items<WALK, ANYHIT>(a, lights, valid, slot, n_node, n_prim, n_seg);
   }
 #ifndef MIRT_PROFILE
   count_add(&my_counters(a.counters)->shadow_node_tests, n_node);

@@ -157,9 +157,13 @@ def test_lane_walk_renders_what_packet_walk_renders(case, host_scenes, device_sc
     a, sa = device_scenes(scene, "packet").render(cam, cfg, 64, 36, 2)
     b, sb = device_scenes(scene, "lane").render(cam, cfg, 64, 36, 2)
     assert np.abs(a - b).max() <= 1e-12
-    for k in ("primary_rays", "secondary_rays", "shadow_segments", "node_tests", "prim_tests", "shadow_node_tests",
-              "shadow_prim_tests"):
+    for k in ("primary_rays", "secondary_rays", "node_tests", "prim_tests"):
         assert sa[k] == sb[k], k
+    # shadow segments: where every primitive is opaque or perfectly clear the packet walk stops a lane at its
+    # first occluder and never tests (or chains through) a clear primitive; the lane walk chains closest hits
+    any_hit = device_scenes(scene, "packet").info()["shadow_any_hit"]
+    for k in ("shadow_segments", "shadow_node_tests", "shadow_prim_tests"):
+        assert (sa[k] <= sb[k]) if any_hit else (sa[k] == sb[k]), k
 
 
 def test_small_queues_split_the_frame_without_changing_it(host_scenes, monkeypatch):
@@ -304,7 +308,10 @@ def test_mixed_point_and_area_lights(tmp_path):
         got, st = ds.render(cam, cfg, 160, 90, 4)
         p, mae = O.psnr(got, ref), float(np.abs(got - ref).mean())
         print(f"mixed lights, {traversal}: PSNR {p:.1f} dB, MAE {mae:.3e}, segments {st['shadow_segments']} / {ost['shadow_segments']}")
-        assert st["shadow_segments"] <= ost["shadow_segments"] and st["shadow_segments"] >= 0.9 * ost["shadow_segments"]
+        # (fewer segments than the oracle's: lights behind the surface are not traced, and the packet walk of a
+        # scene without partly transparent primitives never chains through the clear ones)
+        least = 0.6 if traversal == "packet" and ds.info()["shadow_any_hit"] else 0.9
+        assert st["shadow_segments"] <= ost["shadow_segments"] and st["shadow_segments"] >= least * ost["shadow_segments"]
         assert p >= 60.0 and mae <= 1e-6
 
 
