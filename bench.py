@@ -179,8 +179,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=sorted(PRESETS), default="cfg2")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default=None, help="scene under fixtures/ASCII, or synthetic:<primitives>")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
