@@ -242,7 +242,8 @@ typedef struct mirt_scene_info {
   int32_t n_leaves;
   int32_t wide_depth;      /* its levels below the root */
   int32_t bvh_depth;       /* HOST: depth of desc->nodes */
-  int32_t shadow_any_hit;  /* every primitive is opaque or perfectly clear: shadow rays stop at the first opaque hit */
+  int32_t shadow_any_hit;  /* every primitive is opaque or perfectly clear: shadow rays stop at the first opaque hit
+                              (PACKET and WIDE traversals; MIRT_SHADOW_ANY_HIT=0 in the environment: never) */
   double create_ms;        /* wall clock of mirt_scene_create*, uploads included */
   double tree_ms;          /* of its BVH part (HOST: skip links, 4-wide collapse, upload; DEVICE: the build) */
   double refit_ms;         /* of the last mirt_scene_refit */

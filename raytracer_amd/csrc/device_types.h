@@ -268,8 +268,16 @@ struct TraceArgs {
   int32_t depth;             // depth of the rays this launch traces
   double *accum;             // this rank's tile buffer: a red, a green and a blue plane of fr.plane doubles
   DCounters *counters;       // COUNTER_SHARDS replicas
-  uint32_t first;            // PRIMARY: first 16x16 block of this launch
-  uint32_t n;                // PRIMARY: number of blocks
+  // PRIMARY: this launch renders n 16x16 blocks: the runs of `group` consecutive blocks numbered first, first +
+  // stride, first + 2 stride, ... (blocks >= total do not exist).  The primary launches of a frame interleave
+  // their runs (stride = number of launches), so that each launch is a sample of the whole image and asks the
+  // same of the queues: a launch over the image's top rows alone says nothing about what the floor below spawns.
+  uint32_t first;
+  uint32_t n;
+  uint32_t stride;
+  uint32_t group;
+  uint32_t total;
+  uint32_t pad_;
   unsigned long long *progress;  // PRIMARY, optional: [0] earliest start, [1 + r] latest finish of 16-pixel row band r (wall clock)
   uint32_t *grab;            // k_closest_stream: the next ray number nobody has taken yet (zero at launch)
   DHit *hits;                // k_closest_stream -> k_shade, one per ray number

@@ -1217,9 +1217,14 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       (size_t)QUEUE_SHARDS * ((std::max(ws->ray_shard_cap, ws->shadow_shard_cap) + 255) / 256));
 
   const uint64_t shape_key = grid_total * 1000003ull + (uint64_t)levels * 1009ull + (uint64_t)config->glossy_samples;
+  // A frame shape seen for the first time is probed: after its first primary launch (with all its levels) has
+  // been enqueued, the host waits once and looks at that launch's tails; an overflow restarts the frame with the
+  // split that fits before the other launches have been spent on a frame that would have to be redone.
+  bool probe = false;
   if (sc->split_for != shape_key) {
     sc->split_for = shape_key;
     sc->split = 1;
+    probe = !ws->fixed;
   }
   const bool uv = sc->d.any_maps && config->enable_textures;
   const bool motion = sc->d.any_motion && config->enable_motion_blur && config->sampling == MIRT_SAMPLING_JITTER;
@@ -1228,9 +1233,13 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
   const uint64_t fit = std::min<uint64_t>((uint64_t)(shadow_groups > 1 ? shadow_per : QUEUE_SHARDS) * (ws->shadow_shard_cap / block_items),
                                          (uint64_t)QUEUE_SHARDS * (ws->ray_shard_cap / (size_t)256));
   const uint64_t per_launch = std::max<uint64_t>(1, fit / (uint64_t)spp / sc->split);
-  const size_t chunks = total_blocks ? (size_t)((total_blocks + per_launch - 1) / per_launch) : 0;
+  // the launches interleave runs of `run` consecutive blocks (TraceArgs::first): short enough that every launch
+  // samples the whole image, long enough that blocks rendered at the same time are neighbours
+  const uint64_t run = std::min<uint64_t>(32, per_launch);
+  const uint64_t runs_total = (total_blocks + run - 1) / run, runs_per_launch = per_launch / run;
+  const size_t chunks = total_blocks ? (size_t)((runs_total + runs_per_launch - 1) / runs_per_launch) : 0;
   if (streaming) {
-    const size_t most = std::max<size_t>((size_t)std::min<uint64_t>(per_launch, total_blocks) * (size_t)spp * 256,
+    const size_t most = std::max<size_t>((size_t)std::min<uint64_t>(per_launch, runs_total * run) * (size_t)spp * 256,
                                          levels > 1 ? ws->ray_shard_cap * QUEUE_SHARDS : 0);
     HIP_TRY(ws->hits.reserve(std::max<size_t>(most, 1) * sizeof(DHit)));
     if (uv) HIP_TRY(ws->hits_uv.reserve(std::max<size_t>(most, 1) * sizeof(DHitUV)));
@@ -1275,8 +1284,8 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
     progress = sc->progress.as<unsigned long long>();
   }
   for (size_t c = 0; c < chunks && levels > 0; ++c) {
-    const uint64_t b0 = c * per_launch;
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(per_launch, total_blocks - b0);
+    // launch c takes the runs c, c + chunks, c + 2 chunks, ...
+    const uint32_t nb = (uint32_t)(((runs_total - c + chunks - 1) / chunks) * run);
     for (int depth = 0; depth < levels; ++depth) {
       const bool spawn = depth + 1 < levels;
       TraceArgs a;
@@ -1298,8 +1307,11 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       a.shadow_per = shadow_per;
       a.accum = ws->accum.as<double>();
       a.counters = counters;
-      a.first = (uint32_t)b0;
+      a.first = (uint32_t)c;
       a.n = nb;
+      a.stride = (uint32_t)chunks;
+      a.group = (uint32_t)run;
+      a.total = (uint32_t)total_blocks;
       a.depth = depth;
       a.progress = depth == 0 ? progress : nullptr;
       Timed t{nullptr, nullptr, 0};
@@ -1360,6 +1372,26 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
       }
       ws->launches++;
     }
+    if (probe && c == 0 && chunks > 1) {
+      const size_t first = (size_t)levels * 2 * kCountBytes;
+      HIP_TRY(hipMemcpyAsync(ws->pinned + stats_bytes, ws->control.as<char>() + stats_bytes, first, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      double worst = 0.0;
+      const uint32_t *words = reinterpret_cast<const uint32_t *>(ws->pinned + stats_bytes);
+      for (int level = 0; level < levels; ++level)
+        for (int sh = 0; sh < QUEUE_SHARDS; ++sh) {
+          const size_t at = ((size_t)level * 2) * (kCountBytes / sizeof(uint32_t)) + (size_t)sh * QUEUE_COUNT_STRIDE;
+          worst = std::max(worst, std::max((double)words[at] / (double)std::max<size_t>(ws->ray_shard_cap, 1),
+                                           (double)words[at + kCountBytes / sizeof(uint32_t)] /
+                                               (double)std::max<size_t>(ws->shadow_shard_cap, 1)));
+        }
+      if (worst > 1.0 && per_launch > 1) {
+        uint64_t finer = 2;
+        while ((double)finer < worst * 1.05 && finer < per_launch) finer *= 2;
+        sc->split *= finer;
+        return enqueue_frame(sc, ws);  // (the shape is known now: no second probe)
+      }
+    }
   }
 
   if (n_pixels) {
@@ -1394,6 +1426,7 @@ int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
     ws->pending = false;
     // did every queue shard hold what was appended to it?
     bool overflow = false;
+    double worst = 0.0;  // most any shard was asked to hold, in capacities
     secondary = 0;
     const uint32_t *words = reinterpret_cast<const uint32_t *>(ws->pinned + stats_bytes);
     for (size_t c = 0; c < ws->chunks; ++c)
@@ -1403,6 +1436,8 @@ int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
                             (size_t)s * QUEUE_COUNT_STRIDE;
           const uint32_t rays = words[at], items = words[at + kCountBytes / sizeof(uint32_t)];
           if (rays > ws->ray_shard_cap || items > ws->shadow_shard_cap) overflow = true;
+          worst = std::max(worst, std::max((double)rays / (double)std::max<size_t>(ws->ray_shard_cap, 1),
+                                           (double)items / (double)std::max<size_t>(ws->shadow_shard_cap, 1)));
           secondary += rays;
         }
     if (!overflow) break;
@@ -1410,7 +1445,12 @@ int finish_frame(mirt_scene *sc, mirt_scene::WorkSet *ws, mirt_stats *stats) {
       return fail(MIRT_ERR_MEMORY,
                   "ray queues too small for this frame even one pixel block at a time; raise MIRT_RAY_QUEUE / "
                   "MIRT_SHADOW_QUEUE (entries)");
-    sc->split *= 2;  // render the frame again with finer primary launches
+    // Render the frame again with finer primary launches.  The tails count what was asked for, dropped entries
+    // included, so the split that fits is known in one go (levels below a level that dropped rays saw fewer
+    // than they will: if that makes the estimate too small, the loop comes round again).
+    uint64_t finer = 2;
+    while ((double)finer < worst * 1.05 && finer < ws->per_launch) finer *= 2;
+    sc->split *= finer;
     if (int rc = enqueue_frame(sc, ws)) return rc;
   }
 

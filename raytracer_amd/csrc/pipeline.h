@@ -938,9 +938,18 @@ DEV bool block_pixel(const DFrame &fr, uint32_t block, uint32_t p, int &gx, int 
 // Progress feed (the reference times every image row, Raytracer.cpp:527,573-584): when asked for, a
 // primary block notes the wall clock when it starts and when its samples are shaded, per band of 16
 // pixel rows.  One lane per block, two atomics; nothing when a.progress is NULL.
+// The 16x16 block that virtual block `vb` of a primary launch renders (see TraceArgs::first); false: none.
+DEV bool primary_block(const TraceArgs &a, uint32_t vb, uint32_t &block) {
+  const uint32_t k = vb / (uint32_t)a.fr.spp, run = k / a.group;
+  block = (a.first + run * a.stride) * a.group + (k - run * a.group);
+  if (block < a.total) return true;
+  block = 0;
+  return false;
+}
 DEV void progress_mark(const TraceArgs &a, uint32_t vb, bool finished) {
   if (!a.progress || threadIdx.x != 0) return;
-  const uint32_t block = a.first + vb / (uint32_t)a.fr.spp;
+  uint32_t block;
+  if (!primary_block(a, vb, block)) return;
   int gx, gy;
   uint32_t px;
   block_pixel(a.fr, block, 0, gx, gy, px);
@@ -961,10 +970,11 @@ struct RaySeed {
 // block (Raytracer.cpp:533-541); returns false for lanes outside the image.
 DEV bool primary_ray(const TraceArgs &a, uint32_t vb, uint32_t p, RaySeed &r) {
   const mirt_config &cfg = a.fr.cfg;
-  const uint32_t block = a.first + vb / (uint32_t)a.fr.spp;
+  uint32_t block;
+  const bool exists = primary_block(a, vb, block);
   const uint32_t s = vb % (uint32_t)a.fr.spp;
   int gx, gy;
-  const bool active = block_pixel(a.fr, block, p, gx, gy, r.pixel);
+  const bool active = block_pixel(a.fr, block, p, gx, gy, r.pixel) && exists;
   r.key = mirt_rng_sample_key(cfg.seed, (uint32_t)(gy * a.fr.width + gx), s);
   double u, v;
   if (cfg.sampling == MIRT_SAMPLING_CENTRE) {  // deterministic parity mode
