@@ -785,23 +785,59 @@ int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_optio
   sc->prim_material.resize(s.n_prims);
   sc->prim_motion_index.assign(s.n_prims, -1);
   bool any_maps = false, any_hit = true;
-  for (int i = 0; i < s.n_prims; ++i) {
-    const mirt_prim &p = s.prims[i];
-    DPrim &d = prims[i];
-    DMotion mo;
-    double e[24];
-    prepare_prim(s, p, d, &mo, e);
-    if (d.motion != MOTION_NONE) {
-      d.motion_index = (int32_t)motion.size();
-      sc->prim_motion_index[i] = d.motion_index;
-      motion.push_back(mo);
-      ends.insert(ends.end(), e, e + 24);
+  {
+    // Device records of the primitives.  Large scenes: contiguous ranges on separate threads, each collecting
+    // the motion records of its range; the ranges' records are then appended in order, so the arrays are the ones
+    // the sequential loop would write.
+    struct Range {
+      int a = 0, b = 0;
+      std::vector<DMotion> motion;
+      std::vector<double> ends;
+      bool any_hit = true;
+    };
+    const int n_threads = s.n_prims >= 65536 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
+    std::vector<Range> ranges((size_t)n_threads);
+    auto work = [&](Range &r) {
+      for (int i = r.a; i < r.b; ++i) {
+        const mirt_prim &p = s.prims[i];
+        DPrim &d = prims[i];
+        DMotion mo;
+        double e[24];
+        prepare_prim(s, p, d, &mo, e);
+        if (d.motion != MOTION_NONE) {
+          d.motion_index = (int32_t)r.motion.size();  // within the range; offset added below
+          r.motion.push_back(mo);
+          r.ends.insert(r.ends.end(), e, e + 24);
+        }
+        sc->prim_type[i] = (uint8_t)p.type;
+        sc->prim_material[i] = p.material;
+        const double tr = s.materials[p.material].transparency;
+        transparency[i] = tr;
+        if (tr > 0.0 && tr != 1.0) r.any_hit = false;  // attenuates: shadow segments must be chained through it
+      }
+    };
+    for (int t = 0; t < n_threads; ++t) {
+      ranges[t].a = (int)((long long)s.n_prims * t / n_threads);
+      ranges[t].b = (int)((long long)s.n_prims * (t + 1) / n_threads);
     }
-    sc->prim_type[i] = (uint8_t)p.type;
-    sc->prim_material[i] = p.material;
-    const double tr = s.materials[p.material].transparency;
-    transparency[i] = tr;
-    if (tr > 0.0 && tr != 1.0) any_hit = false;  // attenuates: shadow segments must be chained through it
+    if (n_threads == 1) {
+      work(ranges[0]);
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, std::ref(ranges[t]));
+      for (auto &th : pool) th.join();
+    }
+    for (const Range &r : ranges) {
+      const int32_t base = (int32_t)motion.size();
+      for (int i = r.a; i < r.b && !r.motion.empty(); ++i)
+        if (prims[i].motion != MOTION_NONE) {
+          prims[i].motion_index += base;
+          sc->prim_motion_index[i] = prims[i].motion_index;
+        }
+      motion.insert(motion.end(), r.motion.begin(), r.motion.end());
+      ends.insert(ends.end(), r.ends.begin(), r.ends.end());
+      any_hit = any_hit && r.any_hit;
+    }
   }
   std::vector<mirt_material> materials(s.materials, s.materials + s.n_materials);
   for (const auto &m : materials)
