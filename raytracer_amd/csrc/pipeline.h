@@ -593,7 +593,7 @@ DEV void traverse_wide(const DScene &sc, const RayL &ray, bool active, double t_
   while (wide_step<SHADOW, UV, MOTION>(sc, ray, t_min, closest_t, best, w, deep, n_node, n_prim)) {
   }
   if (!SHADOW) {
-    if (__any(w.tied())) {
+    if (sc.tie_hi > 1.0 && __any(w.tied())) {  // (no band: no tree in the reference's order to walk)
       const unsigned long long bits = (unsigned long long)(uint32_t)*(volatile int32_t *)&deep[WIDE_STACK_DEEP] |
                                       ((unsigned long long)(uint32_t)*(volatile int32_t *)&deep[WIDE_STACK_DEEP + 1] << 32);
       walk_again_in_order<UV, MOTION>(sc, ray, w.tied(), t_min, __longlong_as_double((long long)bits), best, n_node, n_prim);
@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(256) WAVES_PER_SIMD(MIRT_WIDE_WALK_WAVES) void k_cl
   w.start(ray, false);
   for (;;) {
     const bool found = has_ray && !w.busy();  // (or nothing to find)
-    if (__any(found && w.tied()))
+    if (sc.tie_hi > 1.0 && __any(found && w.tied()))  // (no band: no tree in the reference's order to walk)
       walk_again_in_order<UV, MOTION>(sc, ray, found && w.tied(), 1e-5, 1.7976931348623157e308, best, n_node, n_prim);
     if (found) {  // the hit goes out, the lane is free
       hit_store<UV>(a.hits, a.hits_uv, mine, best);

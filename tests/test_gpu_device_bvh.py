@@ -260,6 +260,45 @@ def test_refit_follows_moved_primitives():
         dd.update_prims(19999, prims)  # runs past the end
 
 
+def test_duplicated_primitives_on_the_device_tree():
+    """Every primitive of a cloud present twice, at the same place: each ray's two best hits lie at exactly the
+    same distance.  A tree built on the GPU has no reference order by which to decide between them (the wide walk's
+    second walk in that order needs the reference's tree), so either twin may win -- but a ray that hits must hit,
+    at the distance the oracle finds."""
+    hs = HostScene.synthetic(600, seed=21)
+    n = hs.desc.n_prims
+    twice = (A.Prim * (2 * n))()
+    C.memmove(twice, hs.desc.prims, C.sizeof(A.Prim) * n)
+    C.memmove(C.byref(twice, C.sizeof(A.Prim) * n), hs.desc.prims, C.sizeof(A.Prim) * n)
+    d = type(hs.desc).from_buffer_copy(hs.desc)
+    d.prims, d.n_prims = C.cast(twice, C.POINTER(A.Prim)), 2 * n
+    d.nodes, d.n_nodes, d.leaf_prims, d.n_leaf_prims = None, 0, None, 0
+    dd = DeviceScene(d, 0, builder="device")
+    assert dd.info()["traversal"] == 4
+    cam, _ = hs.camera(0)
+    rng = np.random.default_rng(5)
+    m = 20000
+    centres = np.array([[twice[i].o2w[3], twice[i].o2w[7], twice[i].o2w[11]] for i in range(n)])
+    origin = rng.normal(size=(m, 3))
+    origin = 500.0 * origin / np.linalg.norm(origin, axis=1, keepdims=True)
+    aim = centres[rng.integers(0, n, m)] + rng.normal(scale=0.05, size=(m, 3))
+    dirs = aim - origin
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    got = dd.trace_rays(origin, dirs)
+    ref = O.trace_rays(hs.desc, origin, dirs, None)  # the cloud once, through the oracle
+    kinds = np.array([hs.desc.prims[i].type for i in range(n)] + [-1])
+    plain = (kinds[ref["prim_id"]] != A.MIRT_TORUS) & (kinds[got["prim_id"] % n if n else got["prim_id"]] != A.MIRT_TORUS)
+    hit = (ref["prim_id"] >= 0) & plain
+    print(f"twins: {int(hit.sum())} of {m} rays hit a primitive that is not a torus")
+    assert hit.sum() > 5000
+    assert (got["prim_id"][hit] >= 0).all()
+    assert np.array_equal(got["prim_id"][hit] % n, ref["prim_id"][hit])
+    assert np.allclose(got["t"][hit], ref["t"][hit], rtol=1e-9, atol=0)
+    cfg = default_config(max_ray_depth=3)
+    frame, st = dd.render(cam, cfg, 96, 54, 2)
+    assert np.isfinite(frame).all()
+
+
 def test_moving_primitives_get_the_union_of_their_end_boxes():
     """A primitive with motion blur is boxed by box(matrix_t0) U box(matrix_t1) (Sphere.cpp:85-99), on the
     device as on the host.  A cloud whose spheres fly along x by less than their own width (so that the
