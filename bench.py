@@ -190,7 +190,9 @@ def main():
     ap.add_argument("--glossy-reflection", type=int, default=None)
     ap.add_argument("--depth-of-field", type=float, nargs=2, default=None, metavar=("FSTOP", "FOCUS"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, choices=(1, 2, 3, 4), default=2)
+    ap.add_argument("--frames-in-flight", type=int, choices=(1, 2, 3, 4), default=None,
+                    help="default: 2; 1 for the generated cloud, whose frame is long enough that a second one in flight "
+                         "only competes for the caches")
     ap.add_argument("--builder", choices=("host", "device"), default=None,
                     help="where the BVH is built (default: host; the generated cloud: device)")
     ap.add_argument("--no-caller-times", action="store_true",
@@ -230,6 +232,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     synthetic = args.scene.startswith("synthetic:")
+    if args.frames_in_flight is None:
+        args.frames_in_flight = 1 if synthetic else 2
     if args.builder is None:
         # the generated cloud has no planes: its tree is built on the GPU (12 ms against more than a second
         # on the host); the bundled scenes keep the reference's tree
@@ -436,7 +440,7 @@ def main():
                          "fp64_share": model["fp64_share"] if model else None,
                          "counters_from": model["source"] if model else None,
                          "timed_on": f"{n_timed} frame(s) rendered one at a time after the timed region",
-                         "note": "ms_per_step is the interval between frames with two in flight, frame_latency_ms one "
+                         "note": f"ms_per_step is the interval between frames with {depth} in flight, frame_latency_ms one "
                                  "frame alone; frac = vector issue cycles (double precision 4, other 2 per wave "
                                  "instruction) / (1024 SIMDs x 2.4 GHz x launch time); hbm_frac = measured HBM bytes "
                                  "/ launch time / 8 TB/s; algorithmic_gbs charges every node and primitive test as "
