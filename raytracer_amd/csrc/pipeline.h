@@ -427,12 +427,16 @@ struct WideWalk {
 // ANYHIT (shadow segments of a scene whose primitives are all opaque or perfectly clear): the question is
 // only whether an opaque primitive lies nearer than `any_limit`, so clear primitives are not tested at all
 // and a lane is done with its ray at the first hit nearer than the limit, whichever primitive it is on.
+#ifndef MIRT_WIDE_PAIR
+#define MIRT_WIDE_PAIR 1
+#endif
 template <bool SHADOW, bool UV, bool MOTION, bool ANYHIT = false>
 DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &closest_t, Best<UV> &best, WideWalk &w,
                    int32_t *deep, unsigned &n_node, unsigned &n_prim, double any_limit = 0.0) {
   __shared__ int32_t stack_lds[WIDE_STACK_LDS][256];
   __shared__ int32_t pend[PEND_SLOTS][256];
   const int tid = threadIdx.x;
+  constexpr bool PAIR = MIRT_WIDE_PAIR == 2 || (ANYHIT && MIRT_WIDE_PAIR == 1);
   auto push = [&](int32_t v) {
     if (w.sp < WIDE_STACK_LDS) stack_lds[w.sp][tid] = v;
     else deep[w.sp - WIDE_STACK_LDS] = v;
@@ -482,36 +486,61 @@ DEV bool wide_step(const DScene &sc, const RayL &ray, double t_min, double &clos
     if (walks) {
       const int32_t cur = w.cur;
       if (cur >= 0) {
-        // the whole 128-byte record in eight loads issued together
+        // A wide node: the whole 128-byte record in eight loads issued together.  PAIR (any-hit shadow
+        // segments, whose rays mostly cross the whole scene unoccluded and so visit every node on their way
+        // whatever the order): when the next entry on the stack is a wide node too, it is visited in the same
+        // step -- both records are asked for at once, which halves the dependent fetches of the walk; its
+        // children go onto the stack first, below those of the nearer node, so the order of visits is unchanged.
+        int32_t second = WIDE_NONE;
+        if (PAIR && w.sp > 0) {
+          const int32_t top = w.sp <= WIDE_STACK_LDS ? stack_lds[w.sp - 1][tid] : deep[w.sp - 1 - WIDE_STACK_LDS];
+          if (top >= 0) {
+            second = top;
+            w.sp--;
+          }
+        }
         const flt4v *wq = reinterpret_cast<const flt4v *>(sc.wide + cur);
         const flt4v f0 = wq[0], f1 = wq[1], f2 = wq[2], f3 = wq[3], f4 = wq[4], f5 = wq[5];
         const int4v child = reinterpret_cast<const int4v *>(wq)[6];
         const uint32_t o = reinterpret_cast<const uint32_t *>(wq)[28];
-        const float flo[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-        const float fhi[12] = {f3.x, f3.y, f3.z, f3.w, f4.x, f4.y, f4.z, f4.w, f5.x, f5.y, f5.z, f5.w};
-        auto kid = [&](int i) { return i == 0 ? child.x : i == 1 ? child.y : i == 2 ? child.z : child.w; };
-        n_node += 4;
-        uint32_t hit = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const double lo[3] = {(double)flo[3 * c], (double)flo[3 * c + 1], (double)flo[3 * c + 2]};
-          const double hi[3] = {(double)fhi[3 * c], (double)fhi[3 * c + 1], (double)fhi[3 * c + 2]};
-          if (box_hit_v(lo, hi, ray, t_min, closest_t)) hit |= 1u << c;
+        flt4v g0 = f0, g1 = f1, g2 = f2, g3 = f3, g4 = f4, g5 = f5;
+        int4v child2 = child;
+        uint32_t o2 = o;
+        if (PAIR && second != WIDE_NONE) {
+          const flt4v *wq2 = reinterpret_cast<const flt4v *>(sc.wide + second);
+          g0 = wq2[0]; g1 = wq2[1]; g2 = wq2[2]; g3 = wq2[3]; g4 = wq2[4]; g5 = wq2[5];
+          child2 = reinterpret_cast<const int4v *>(wq2)[6];
+          o2 = reinterpret_cast<const uint32_t *>(wq2)[28];
         }
         // Visiting order of the binary ordered walk: the top node's two children, nearer first,
         // and within each its own two children, nearer first.  order: 3 bits per binary node
         // (top, first child, second child): axis, and bit 2 = the second child is the lower one.
-        const uint32_t up = w.up;
-        const bool t2 = (((o >> 2) & 1u) != 0) == (((up >> (o & 3u)) & 1u) != 0);
-        const bool a2 = (((o >> 5) & 1u) != 0) == (((up >> ((o >> 3) & 3u)) & 1u) != 0);
-        const bool b2 = (((o >> 8) & 1u) != 0) == (((up >> ((o >> 6) & 3u)) & 1u) != 0);
-        const int an = a2 ? 1 : 0, bn = b2 ? 3 : 2;  // the nearer slot of each pair
-        const int s0 = t2 ? bn : an, s1 = s0 ^ 1, s2 = t2 ? an : bn, s3 = s2 ^ 1;
-        // farthest first onto the stack, so that the nearest comes off first
-        if (hit & (1u << s3)) push(kid(s3));
-        if (hit & (1u << s2)) push(kid(s2));
-        if (hit & (1u << s1)) push(kid(s1));
-        if (hit & (1u << s0)) push(kid(s0));
+        auto visit = [&](flt4v a0, flt4v a1, flt4v a2_, flt4v a3, flt4v a4, flt4v a5, int4v ch, uint32_t ord) {
+          const float flo[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2_.x, a2_.y, a2_.z, a2_.w};
+          const float fhi[12] = {a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w, a5.x, a5.y, a5.z, a5.w};
+          auto kid = [&](int i) { return i == 0 ? ch.x : i == 1 ? ch.y : i == 2 ? ch.z : ch.w; };
+          n_node += 4;
+          uint32_t hit = 0;
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const double lo[3] = {(double)flo[3 * c], (double)flo[3 * c + 1], (double)flo[3 * c + 2]};
+            const double hi[3] = {(double)fhi[3 * c], (double)fhi[3 * c + 1], (double)fhi[3 * c + 2]};
+            if (box_hit_v(lo, hi, ray, t_min, closest_t)) hit |= 1u << c;
+          }
+          const uint32_t up = w.up;
+          const bool t2 = (((ord >> 2) & 1u) != 0) == (((up >> (ord & 3u)) & 1u) != 0);
+          const bool a2 = (((ord >> 5) & 1u) != 0) == (((up >> ((ord >> 3) & 3u)) & 1u) != 0);
+          const bool b2 = (((ord >> 8) & 1u) != 0) == (((up >> ((ord >> 6) & 3u)) & 1u) != 0);
+          const int an = a2 ? 1 : 0, bn = b2 ? 3 : 2;  // the nearer slot of each pair
+          const int s0 = t2 ? bn : an, s1 = s0 ^ 1, s2 = t2 ? an : bn, s3 = s2 ^ 1;
+          // farthest first onto the stack, so that the nearest comes off first
+          if (hit & (1u << s3)) push(kid(s3));
+          if (hit & (1u << s2)) push(kid(s2));
+          if (hit & (1u << s1)) push(kid(s1));
+          if (hit & (1u << s0)) push(kid(s0));
+        };
+        if (PAIR && second != WIDE_NONE) visit(g0, g1, g2, g3, g4, g5, child2, o2);
+        visit(f0, f1, f2, f3, f4, f5, child, o);
       } else {
         const dbl2 *lq = reinterpret_cast<const dbl2 *>(sc.leaves + ~cur);
         const dbl2 l0 = lq[0], l1 = lq[1], l2 = lq[2];
