@@ -377,6 +377,10 @@ int mirt_scene_set_traversal(mirt_scene *scene, int mode);
 #define MIRT_GROUP_TILE 16
 typedef struct mirt_group mirt_group;
 int mirt_group_create(const mirt_scene_desc *desc, const int *devices, int n_devices, mirt_group **out);
+/* The same with build options for every member's replica (mirt_scene_create_with): with MIRT_BUILDER_DEVICE each
+ * GPU builds its own tree from the primitives, and `desc` need not carry one. */
+int mirt_group_create_with(const mirt_scene_desc *desc, const int *devices, int n_devices,
+                           const mirt_build_options *options, mirt_group **out);
 void mirt_group_destroy(mirt_group *group);
 int mirt_group_size(const mirt_group *group);
 const char *mirt_group_transport(const mirt_group *group);

@@ -108,7 +108,7 @@ ENGINE_SYMBOLS = [
     "mirt_device_count", "mirt_config_defaults", "mirt_scene_create", "mirt_scene_destroy", "mirt_render",
     "mirt_render_tiles", "mirt_tile_buffer_pixels", "mirt_trace_ids", "mirt_trace_rays", "mirt_scene_set_traversal", "mirt_render_tiles_begin", "mirt_render_tiles_end",
     "mirt_last_error", "mirt_abi_version", "mirt_render_tiles_noalloc", "mirt_noalloc_scratch_bytes",
-    "mirt_group_create", "mirt_group_destroy", "mirt_group_size", "mirt_group_transport", "mirt_group_set_traversal",
+    "mirt_group_create", "mirt_group_create_with", "mirt_group_destroy", "mirt_group_size", "mirt_group_transport", "mirt_group_set_traversal",
     "mirt_group_render", "mirt_scene_record_progress", "mirt_scene_progress",
 ]
 
@@ -137,6 +137,8 @@ def _declare_engine(lib):
     lib.mirt_scene_record_progress.argtypes = [C.c_void_p, C.c_int]
     lib.mirt_scene_progress.argtypes = [C.c_void_p, dp, C.c_int]
     lib.mirt_group_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    lib.mirt_group_create_with.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions),
+                                           C.POINTER(C.c_void_p)]
     lib.mirt_group_destroy.argtypes = [C.c_void_p]
     lib.mirt_group_destroy.restype = None
     lib.mirt_group_size.argtypes = [C.c_void_p]

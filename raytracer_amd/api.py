@@ -235,13 +235,18 @@ class DeviceGroup:
     """A scene replicated on several GPUs of this process (mirt_group_create); frames are split into
     16x16 tiles dealt round-robin and gathered on the first device."""
 
-    def __init__(self, scene, devices):
+    def __init__(self, scene, devices, builder="host", leaf_size=0):
+        """builder / leaf_size: as for DeviceScene, for every member's replica (mirt_group_create_with)."""
         self._lib = A.engine_lib()
         self._h = C.c_void_p()
         desc = scene.desc if isinstance(scene, HostScene) else scene
         self._keep = scene
         devs = (C.c_int * len(devices))(*devices)
-        _check(self._lib.mirt_group_create(C.byref(desc), devs, len(devices), C.byref(self._h)), "mirt_group_create")
+        opts = A.BuildOptions()
+        opts.builder = {"host": A.MIRT_BUILDER_HOST, "device": A.MIRT_BUILDER_DEVICE}[builder]
+        opts.leaf_size = leaf_size
+        _check(self._lib.mirt_group_create_with(C.byref(desc), devs, len(devices), C.byref(opts), C.byref(self._h)),
+               "mirt_group_create_with")
         self.devices = list(devices)
 
     @property

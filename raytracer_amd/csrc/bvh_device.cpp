@@ -39,6 +39,7 @@ void DeviceBvh::release() {
 int DeviceBvh::build(hipStream_t stream, const DPrim *d_prims, const double *d_motion_ends,
                      const double *d_transparency, uint32_t n, uint32_t leaf_max) {
   const auto t0 = std::chrono::steady_clock::now();
+  (void)hipGetLastError();  // what an earlier, unrelated call of this thread left behind is not this build's error
   release();
   std::memset(&a_, 0, sizeof a_);
   a_.prims = d_prims;
@@ -173,6 +174,7 @@ int DeviceBvh::build(hipStream_t stream, const DPrim *d_prims, const double *d_m
 
 int DeviceBvh::refit(hipStream_t stream, const double *d_motion_ends) {
   const auto t0 = std::chrono::steady_clock::now();
+  (void)hipGetLastError();
   if (a_.n == 0) return 0;
   if (!block_) {
     error = "no device-built tree to refit";

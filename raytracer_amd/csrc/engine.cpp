@@ -1723,6 +1723,7 @@ MIRT_API int mirt_trace_ids(mirt_scene *scene, const mirt_camera *camera, int wi
                             double *t, double *normal, double *uv) {
   if (!scene || !camera || !prim_id) return fail(MIRT_ERR_INVALID, "NULL argument");
   if (width <= 0 || height <= 0) return fail(MIRT_ERR_INVALID, "width and height must be positive");
+  (void)hipGetLastError();  // an error some earlier, failed call left behind is not this call's
   HIP_TRY(hipSetDevice(scene->device));
   const size_t n = (size_t)width * height;
   // layout: ids | t | normal | uv
@@ -1759,6 +1760,7 @@ MIRT_API int mirt_trace_rays(mirt_scene *scene, int64_t n, const double *origin,
   if (!scene || !origin || !dir || !prim_id) return fail(MIRT_ERR_INVALID, "NULL argument");
   if (n < 0 || n > 0x7fffffff) return fail(MIRT_ERR_INVALID, "ray count out of range");
   if (n == 0) return MIRT_OK;
+  (void)hipGetLastError();  // an error some earlier, failed call left behind is not this call's
   HIP_TRY(hipSetDevice(scene->device));
   const size_t N = (size_t)n;
   // layout: origin 3N | dir 3N | time N | t_max N | t N | normal 3N | ids N

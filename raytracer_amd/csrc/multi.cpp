@@ -199,6 +199,11 @@ MIRT_API void mirt_group_destroy(mirt_group *g) {
 }
 
 MIRT_API int mirt_group_create(const mirt_scene_desc *desc, const int *devices, int n_devices, mirt_group **out) {
+  return mirt_group_create_with(desc, devices, n_devices, nullptr, out);
+}
+
+MIRT_API int mirt_group_create_with(const mirt_scene_desc *desc, const int *devices, int n_devices,
+                                    const mirt_build_options *options, mirt_group **out) {
   if (!out) return mirt_fail(MIRT_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!devices || n_devices < 1 || n_devices > MIRT_GROUP_MAX)
@@ -217,7 +222,7 @@ MIRT_API int mirt_group_create(const mirt_scene_desc *desc, const int *devices, 
   for (int i = 0; i < n_devices; ++i) {
     Member &mb = g->m[i];
     mb.device = devices[i];
-    if (int rc = mirt_scene_create(desc, devices[i], &mb.scene)) return rc;  // a replica per member
+    if (int rc = mirt_scene_create_with(desc, devices[i], options, &mb.scene)) return rc;  // a replica per member
     HIP_TRY(hipSetDevice(mb.device));
     for (int s = 0; s < MIRT_GROUP_SLOTS; ++s) {
       HIP_TRY(hipStreamCreateWithFlags(&mb.stream[s], hipStreamNonBlocking));

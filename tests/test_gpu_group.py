@@ -73,6 +73,25 @@ def test_group_on_a_large_scene_and_bad_arguments(host_scenes):
         DeviceGroup(hs, [99])
 
 
+def test_group_whose_members_build_their_own_trees():
+    """mirt_group_create_with(MIRT_BUILDER_DEVICE): every member builds its BVH on its GPU from a description
+    without a tree; the frame is the one a single scene built the same way renders."""
+    from raytracer_amd import HostScene, DeviceScene, MirtError
+    hs = HostScene.synthetic(20000, build_tree=False)
+    assert hs.desc.n_nodes == 0
+    cam, _ = hs.camera(0)
+    cfg = default_config(max_ray_depth=3)
+    one = DeviceScene(hs, 0, builder="device")
+    want, wst = one.render(cam, cfg, 192, 108, 2)
+    grp = DeviceGroup(hs, [0, 0, 0], builder="device")
+    got, st, members = grp.render(cam, cfg, 192, 108, 2)
+    assert len(members) == 3 and st["primary_rays"] == wst["primary_rays"] == 192 * 108 * 2
+    assert np.abs(got - want).max() <= 1e-12
+    grp.close()
+    with pytest.raises(MirtError):
+        DeviceGroup(hs, [0, 0])  # the reference-order builder needs the description's tree
+
+
 def test_group_frames_in_flight_and_device_output(host_scenes, device_scenes):
     """mirt_group_render_begin / _end: two frames in flight in the two slots, frame i read back while frame
     i + 1 renders, and the frame left on the first device (mirt_group_frame)."""
