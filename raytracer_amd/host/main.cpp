@@ -34,6 +34,7 @@ void print_help(const char *prog) {
             << "  --seed <n>               Seed of the sampling sequence (default: 0)\n"
             << "  --device <n>             HIP device to render on (default: 0)\n"
             << "  --devices <n>            Split every frame over n GPUs, device .. device + n - 1 (default: 1)\n"
+            << "  --gpu-bvh                Build the BVH on the GPU (large scenes without planes)\n"
             << "  --binary-ppm             Write the image as binary PPM (P6) instead of ASCII (P3)\n"
             << "  --help                   Display this help message\n";
 }
@@ -78,6 +79,7 @@ void parse_arguments(int argc, char *argv[]) {
     else if (a == "--seed" && left >= 1) g_config.seed = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "--device" && left >= 1) g_config.device = std::atoi(argv[++i]);
     else if (a == "--devices" && left >= 1) g_config.devices = std::max(1, std::atoi(argv[++i]));
+    else if (a == "--gpu-bvh") g_config.gpu_bvh = true;
     else if (a == "--binary-ppm") g_config.output_format = "p6";
     else {
       host_log(LogLevel::Error, "Unknown argument arg=%s", a.c_str());

@@ -197,6 +197,8 @@ struct RenderConfig {
   unsigned long long seed = 0;
   int device = 0;
   int devices = 1;
+  // build the BVH on the GPU instead of with build_bvh (large scenes without planes; mirt_scene_create_with)
+  bool gpu_bvh = false;
 };
 extern RenderConfig g_config;
 

@@ -20,7 +20,7 @@ Raytracer::Raytracer(const Scene &s) : scene(s), stats(new mirt_stats) {
   std::memset(stats.get(), 0, sizeof(mirt_stats));
   host_log(LogLevel::Info, "Initializing Raytracer and building BVH...");
   const auto t0 = std::chrono::steady_clock::now();
-  flat.reset(new FlatScene(flatten_scene(scene)));
+  flat.reset(new FlatScene(flatten_scene(scene, "", !g_config.gpu_bvh)));  // (--gpu-bvh: the engine builds the tree)
   const auto ms =
       std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
   host_log(LogLevel::Info, "BVH construction complete! duration_ms=%lld", static_cast<long long>(ms));
@@ -28,17 +28,20 @@ Raytracer::Raytracer(const Scene &s) : scene(s), stats(new mirt_stats) {
            flat->max_depth);
   host_log(LogLevel::Info, "Preloaded textures count=%d", static_cast<int>(flat->textures.size()));
   const mirt_scene_desc d = flat->desc();
+  mirt_build_options build;
+  std::memset(&build, 0, sizeof build);
+  build.builder = g_config.gpu_bvh ? MIRT_BUILDER_DEVICE : MIRT_BUILDER_HOST;
   if (g_config.devices > 1) {
     // the frame's tiles are dealt to `devices` GPUs, each with its own replica of the scene
     std::vector<int> devs;
     // (MIRT_DEVICES_SAME=1 puts every member on `device`: a rehearsal of the several-GPU path on one GPU)
     const bool same = std::getenv("MIRT_DEVICES_SAME") != nullptr;
     for (int i = 0; i < g_config.devices; ++i) devs.push_back(g_config.device + (same ? 0 : i));
-    if (mirt_group_create(&d, devs.data(), g_config.devices, &device_group) != MIRT_OK)
+    if (mirt_group_create_with(&d, devs.data(), g_config.devices, &build, &device_group) != MIRT_OK)
       throw std::runtime_error(std::string("mirt_group_create: ") + mirt_last_error());
     host_log(LogLevel::Info, "Rendering on %d GPUs, frame gathered by %s", g_config.devices,
              mirt_group_transport(device_group));
-  } else if (mirt_scene_create(&d, g_config.device, &device_scene) != MIRT_OK) {
+  } else if (mirt_scene_create_with(&d, g_config.device, &build, &device_scene) != MIRT_OK) {
     throw std::runtime_error(std::string("mirt_scene_create: ") + mirt_last_error());
   }
 }

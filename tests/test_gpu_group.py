@@ -198,6 +198,34 @@ def test_cli_devices_flag(tmp_path):
     assert (np.abs(a - b) > 1e-9).mean() < 1e-4  # a value on a rounding boundary may flip with the order of the sums
 
 
+def test_cli_gpu_bvh_flag(tmp_path):
+    """`raytracer --gpu-bvh` renders a generated cloud (written out as an ASCII scene file) with the tree built on
+    the GPU -- alone and with --devices 2 -- and gets the image of the reference's own tree up to the handful of
+    pixels whose far tori the two trees test differently; a scene with planes is refused with a message."""
+    import os
+    from raytracer_amd import HostScene
+    cli = os.path.join(ROOT, "raytracer_amd", "bin", "raytracer")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    (tmp_path / "ASCII").mkdir()
+    HostScene.synthetic(3000, seed=5).write_ascii(str(tmp_path / "ASCII" / "cloud.txt"))
+    args = ["--scene", "ASCII/cloud.txt", "--resolution", "160", "90", "--samples", "2", "--max-depth", "3", "--binary-ppm"]
+    out = {k: str(tmp_path / f"{k}.ppm") for k in ("host", "gpu", "gpu2")}
+    env = dict(os.environ, MIRT_DEVICES_SAME="1")
+    for k, extra in (("host", []), ("gpu", ["--gpu-bvh"]), ("gpu2", ["--gpu-bvh", "--devices", "2"])):
+        r = subprocess.run([cli, *args, *extra, "--output", out[k]], cwd=tmp_path, capture_output=True, text=True,
+                           timeout=120, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+    a, _ = read_ppm(out["host"])
+    b, _ = read_ppm(out["gpu"])
+    c, _ = read_ppm(out["gpu2"])
+    assert (np.abs(a - b) > 1e-9).mean() < 5e-3
+    assert (np.abs(b - c) > 1e-9).mean() < 1e-4
+    r = subprocess.run([cli, "--scene", "ASCII/Test5.txt", "--resolution", "64", "36", "--gpu-bvh", "--output", str(tmp_path / "x.ppm")],
+                       cwd=FIXTURES, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "planes" in r.stdout + r.stderr
+
+
 def test_progress_feed_and_render_recipes(host_scenes, tmp_path):
     """mirt_scene_record_progress / mirt_scene_progress, the row-times CSV of the drop-in renderer
     (written, like the reference's, when Output/ exists in the working directory), and the reference
