@@ -244,70 +244,106 @@ FlatScene scene(const SceneT &scene, const std::string &texture_root = "", bool 
 
   Builder b;
   b.out = &fs;
-  const std::size_t total = scene.spheres.size() + scene.cubes.size() + scene.planes.size() + scene.toruses.size() +
-                            scene.cylinders.size() + scene.cones.size();
-  fs.prims.reserve(total);
-  fs.materials.reserve(total);
-  b.boxes.reserve(total);
-  b.centres.reserve(3 * total);
-  auto add = [&](const auto &s, mirt_prim p, const Box &box, const auto &centre) {
-    fs.materials.push_back(material(s.material, reg));
-    fs.prims.push_back(p);
-    b.boxes.push_back(box);
-    b.centres.insert(b.centres.end(), {centre.x, centre.y, centre.z});
+  // Global primitive numbering (Bvh.cpp:244-304): spheres, cubes, planes, toruses, cylinders, cones.  Every
+  // primitive has its own material record, so a primitive's index is also its material's; the records of a
+  // kind are independent of one another and large kinds are filled on several threads.
+  const std::size_t n_kind[6] = {scene.spheres.size(), scene.cubes.size(),     scene.planes.size(),
+                                 scene.toruses.size(), scene.cylinders.size(), scene.cones.size()};
+  std::size_t first[6], total = 0;
+  for (int k = 0; k < 6; ++k) {
+    first[k] = total;
+    total += n_kind[k];
+  }
+  fs.prims.resize(total);
+  fs.materials.resize(total);
+  b.boxes.resize(total);
+  b.centres.resize(3 * total);
+  auto put = [&](std::size_t at, const auto &s, const mirt_prim &p, const Box &box, const auto &centre) {
+    fs.materials[at] = material(s.material, reg);
+    fs.prims[at] = p;
+    b.boxes[at] = box;
+    b.centres[3 * at] = centre.x;
+    b.centres[3 * at + 1] = centre.y;
+    b.centres[3 * at + 2] = centre.z;
+  };
+  auto for_each_index = [](std::size_t n, auto &&body) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const std::size_t n_threads = n >= 16384 ? std::min<std::size_t>(std::min(hw, 16u), n / 8192) : 1;
+    if (n_threads <= 1) {
+      for (std::size_t i = 0; i < n; ++i) body(i);
+      return;
+    }
+    std::vector<std::thread> pool;
+    for (std::size_t t = 0; t < n_threads; ++t)
+      pool.emplace_back([&body, n, t, n_threads]() {
+        for (std::size_t i = n * t / n_threads; i < n * (t + 1) / n_threads; ++i) body(i);
+      });
+    for (auto &th : pool) th.join();
   };
   const double unit_lo[3] = {-1, -1, -1}, unit_hi[3] = {1, 1, 1};
-  auto next_material = [&fs]() { return static_cast<int>(fs.materials.size()); };
 
-  for (const auto &s : scene.spheres)
-    add(s, base_prim(s, MIRT_SPHERE, next_material()), world_box(s, unit_lo, unit_hi), s.location);
-  for (const auto &s : scene.cubes) {
-    mirt_prim p = base_prim(s, MIRT_CUBE, next_material());
+  for_each_index(n_kind[0], [&](std::size_t i) {
+    const auto &s = scene.spheres[i];
+    const std::size_t at = first[0] + i;
+    put(at, s, base_prim(s, MIRT_SPHERE, static_cast<int>(at)), world_box(s, unit_lo, unit_hi), s.location);
+  });
+  for_each_index(n_kind[1], [&](std::size_t i) {
+    const auto &s = scene.cubes[i];
+    const std::size_t at = first[1] + i;
+    mirt_prim p = base_prim(s, MIRT_CUBE, static_cast<int>(at));
     p.param[0] = s.scale.x; p.param[1] = s.scale.y; p.param[2] = s.scale.z;  // box UVs (Cube.cpp:106-131)
-    add(s, p, world_box(s, unit_lo, unit_hi), s.translation);
-  }
-  for (const auto &s : scene.planes) {
-    mirt_prim p = base_prim(s, MIRT_PLANE, next_material());
+    put(at, s, p, world_box(s, unit_lo, unit_hi), s.translation);
+  });
+  for (std::size_t i = 0; i < n_kind[2]; ++i) {  // (planes append their corner points: one after the other)
+    const auto &s = scene.planes[i];
+    const std::size_t at = first[2] + i;
+    mirt_prim p = base_prim(s, MIRT_PLANE, static_cast<int>(at));
     p.first_point = static_cast<int32_t>(fs.plane_points.size() / 3);
     p.n_points = static_cast<int32_t>(s.points.size());
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     using PointT = typename std::decay_t<decltype(s.points)>::value_type;
     PointT centre(0, 0, 0);
-    for (std::size_t i = 0; i < s.points.size(); ++i) {
-      const auto &q = s.points[i];
+    for (std::size_t j = 0; j < s.points.size(); ++j) {
+      const auto &q = s.points[j];
       fs.plane_points.insert(fs.plane_points.end(), {q.x, q.y, q.z});
       const double v[3] = {q.x, q.y, q.z};
       for (int a = 0; a < 3; ++a) {
-        lo[a] = i == 0 ? v[a] : std::min(lo[a], v[a]);
-        hi[a] = i == 0 ? v[a] : std::max(hi[a], v[a]);
+        lo[a] = j == 0 ? v[a] : std::min(lo[a], v[a]);
+        hi[a] = j == 0 ? v[a] : std::max(hi[a], v[a]);
       }
       centre = centre + q;
     }
     if (!s.points.empty()) centre = centre * (1.0 / s.points.size());
     // an empty plane keeps the degenerate box at the origin un-transformed (Plane.cpp:136-138)
-    add(s, p, s.points.empty() ? Box{{0, 0, 0}, {0, 0, 0}} : world_box(s, lo, hi), centre);
+    put(at, s, p, s.points.empty() ? Box{{0, 0, 0}, {0, 0, 0}} : world_box(s, lo, hi), centre);
   }
-  for (const auto &s : scene.toruses) {
-    mirt_prim p = base_prim(s, MIRT_TORUS, next_material());
+  for_each_index(n_kind[3], [&](std::size_t i) {
+    const auto &s = scene.toruses[i];
+    const std::size_t at = first[3] + i;
+    mirt_prim p = base_prim(s, MIRT_TORUS, static_cast<int>(at));
     p.param[0] = s.major_radius; p.param[1] = s.minor_radius;
     const double R = s.major_radius + s.minor_radius, r = s.minor_radius;
     const double lo[3] = {-R, -R, -r}, hi[3] = {R, R, r};
-    add(s, p, world_box(s, lo, hi), s.location);
-  }
-  for (const auto &s : scene.cylinders) {
-    mirt_prim p = base_prim(s, MIRT_CYLINDER, next_material());
+    put(at, s, p, world_box(s, lo, hi), s.location);
+  });
+  for_each_index(n_kind[4], [&](std::size_t i) {
+    const auto &s = scene.cylinders[i];
+    const std::size_t at = first[4] + i;
+    mirt_prim p = base_prim(s, MIRT_CYLINDER, static_cast<int>(at));
     p.param[0] = s.radius; p.param[1] = s.depth;
     const double r = s.radius, h = s.depth / 2.0;
     const double lo[3] = {-r, -r, -h}, hi[3] = {r, r, h};
-    add(s, p, world_box(s, lo, hi), s.location);
-  }
-  for (const auto &s : scene.cones) {
-    mirt_prim p = base_prim(s, MIRT_CONE, next_material());
+    put(at, s, p, world_box(s, lo, hi), s.location);
+  });
+  for_each_index(n_kind[5], [&](std::size_t i) {
+    const auto &s = scene.cones[i];
+    const std::size_t at = first[5] + i;
+    mirt_prim p = base_prim(s, MIRT_CONE, static_cast<int>(at));
     p.param[0] = s.radius; p.param[1] = s.depth;
     const double r = s.radius, h = s.depth / 2.0;
     const double lo[3] = {-r, -r, -h}, hi[3] = {r, r, h};
-    add(s, p, world_box(s, lo, hi), s.location);
-  }
+    put(at, s, p, world_box(s, lo, hi), s.location);
+  });
 
   if (build_tree) {
     b.order.resize(total);
