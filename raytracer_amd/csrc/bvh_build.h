@@ -154,26 +154,34 @@ __global__ __launch_bounds__(64) void k_sort_hist(const BuildArgs a) {
 }
 
 // exclusive prefix sum over the 256 x sort_blocks counts, digit-major: where each block's keys of each
-// digit start in the output
+// digit start in the output.  One block of 16 waves; wave w owns a contiguous sixteenth of the counts and goes
+// through it 64 at a time (one coalesced load, a shuffle scan, a running carry): once to total it, and --
+// after the 16 totals have been scanned -- once more to write the prefixes.
 __global__ __launch_bounds__(1024) void k_sort_scan(const BuildArgs a) {
-  __shared__ uint32_t part[1024];
-  const uint32_t total = 256u * a.sort_blocks, per = (total + 1023u) / 1024u;
-  const uint32_t lo = threadIdx.x * per, hi = lo + per < total ? lo + per : total;
+  __shared__ uint32_t part[16];
+  const uint32_t total = 256u * a.sort_blocks;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t per = ((total + 15u) / 16u + 63u) & ~63u;  // counts per wave, a multiple of 64
+  const uint32_t lo = wave * per, hi = lo + per < total ? lo + per : total;
   uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += a.hist[i];
-  part[threadIdx.x] = s;
+  for (uint32_t i = lo + lane; i < hi; i += 64) s += a.hist[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) part[wave] = s;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[threadIdx.x] - s;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t c = a.hist[i];
-    a.hist[i] = run;
-    run += c;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < wave; w++) carry += part[w];
+  for (uint32_t base = lo; base < hi; base += 64) {
+    const uint32_t i = base + lane;
+    const uint32_t c = i < hi ? a.hist[i] : 0;
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off);
+      if (lane >= (uint32_t)off) incl += v;
+    }
+    if (i < hi) a.hist[i] = carry + incl - c;
+    carry += __shfl(incl, 63);
   }
 }
 
