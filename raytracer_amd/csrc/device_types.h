@@ -335,7 +335,8 @@ void launch_deinterleave(unsigned grid, void *stream, const DeinterleaveArgs &a)
 // uv: the scene samples image maps, so hits carry texture coordinates and a tangent frame;
 // motion: some ray of the launch may be at a shutter time other than 0.5.
 void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, void *stream, const TraceArgs &a);
-void launch_shadow(int walk, bool strata, bool any_hit, unsigned grid, void *stream, const ShadowArgs &a);  // strata: some light has more than one
+// strata: some light has more than one; point: no light is an area light
+void launch_shadow(int walk, bool strata, bool any_hit, bool point, unsigned grid, void *stream, const ShadowArgs &a);
 // wide walk, resident grid; any_hit: segments end at the first opaque hit (DScene::shadow_any_hit)
 void launch_shadow_stream(bool any_hit, unsigned grid, void *stream, const ShadowArgs &a);
 // wide walk, two launches: closest hits by a resident grid, then shading with one lane per ray

@@ -197,6 +197,7 @@ struct mirt_scene {
   int light_frame_for = 0;  // shadow_samples the device copy of the lights' strata was made for
   bool light_frame_valid = false;
   bool any_strata = false;  // some light of the current light-frame table has more than one stratum
+  bool point_lights = false;  // no light of the scene is an area light
   // frame to a caller's host buffer: pinned staging memory and one event per piece (copy_frame_out)
   static constexpr int kStagePieces = 4;
   char *stage = nullptr;
@@ -860,6 +861,9 @@ int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_optio
     textures[i].pad = 0;
   }
   sc->host_lights.assign(s.lights, s.lights + s.n_lights);
+  sc->point_lights = true;
+  for (const mirt_light &L : sc->host_lights)
+    if (L.type == MIRT_LIGHT_AREA) sc->point_lights = false;
 
   HIP_TRY(upload(sc->prims, prims));
   HIP_TRY(upload(sc->motion, motion));
@@ -1399,7 +1403,7 @@ int enqueue_frame(mirt_scene *sc, mirt_scene::WorkSet *ws) {
         sa.grab = a.shadow_count + 1;  // a spare word of the launch's tail block, zeroed with it
         launch_shadow_stream(sc->d.shadow_any_hit != 0, sc->resident_grid, stream, sa);
       } else {
-        launch_shadow(sc->walk, sc->any_strata, sc->d.shadow_any_hit != 0, consumer_grid, stream, sa);
+        launch_shadow(sc->walk, sc->any_strata, sc->d.shadow_any_hit != 0, sc->point_lights, consumer_grid, stream, sa);
       }
       HIP_TRY(hipGetLastError());
       if (kernel_timing) {

@@ -61,7 +61,11 @@ void launch_trace(int walk, bool primary, bool uv, bool motion, unsigned grid, v
           launch_trace_w<WALK_WIDE>(primary, uv, motion, grid, st, a));
 }
 
-template <bool STRATA> static void launch_shadow_t(int walk, bool any_hit, unsigned grid, hipStream_t st, const ShadowArgs &a) {
+template <bool STRATA> static void launch_shadow_t(int walk, bool any_hit, bool point, unsigned grid, hipStream_t st, const ShadowArgs &a) {
+  if (any_hit && point && !STRATA && walk == WALK_PACKET && (MIRT_WALKS & 1)) {
+    IF_PACKET(hipLaunchKernelGGL((k_shadow<WALK_PACKET, false, true, true>), dim3(grid), dim3(256), 0, st, a));
+    return;
+  }
   if (any_hit && walk == WALK_PACKET && (MIRT_WALKS & 1)) {
     IF_PACKET(hipLaunchKernelGGL((k_shadow<WALK_PACKET, STRATA, true>), dim3(grid), dim3(256), 0, st, a));
     return;
@@ -72,10 +76,11 @@ template <bool STRATA> static void launch_shadow_t(int walk, bool any_hit, unsig
           hipLaunchKernelGGL((k_shadow<WALK_WIDE, STRATA>), dim3(grid), dim3(256), 0, st, a));
 }
 // any_hit: the scene allows it (DScene::shadow_any_hit); used by the packet walk, ignored by the others
-void launch_shadow(int walk, bool strata, bool any_hit, unsigned grid, void *stream, const ShadowArgs &a) {
+// point: no light is an area light (with any_hit and without strata the packet walk then runs its shortest form)
+void launch_shadow(int walk, bool strata, bool any_hit, bool point, unsigned grid, void *stream, const ShadowArgs &a) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (strata) launch_shadow_t<true>(walk, any_hit, grid, st, a);
-  else launch_shadow_t<false>(walk, any_hit, grid, st, a);
+  if (strata) launch_shadow_t<true>(walk, any_hit, point, grid, st, a);
+  else launch_shadow_t<false>(walk, any_hit, point, grid, st, a);
 }
 
 template <bool PRIMARY, bool UV, bool MOTION>
