@@ -19,8 +19,12 @@ HOST_SRCS := $(HOST)/mirt_math.cpp $(HOST)/scene_loader.cpp $(HOST)/image_io.cpp
              $(HOST)/render.cpp $(HOST)/capi.cpp $(HOST)/synthetic.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.h) include/mirt.h
 
+# -disable-machine-licm: the kernels are one long loop (the walk) around every intersector; hoisting each
+# double-precision literal and address out of it costs more registers than a kernel has, and the allocator
+# then parks them in vector-register lanes and reads them back inside the loop (k_trace: 168 registers
+# and scratch with it, 139 and none without)
 HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function \
-            -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden $(EXTRA_HIPFLAGS)
+            -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden -mllvm -disable-machine-licm $(EXTRA_HIPFLAGS)
 # no FMA contraction on the host: the matrices and boxes computed here are compared bit for bit
 # with the reference's
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -pthread -Wall -Wextra -Iinclude -I$(HOST)

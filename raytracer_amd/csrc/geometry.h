@@ -164,6 +164,38 @@ struct XfG {
   DEV d3 world_normal(d3 n) const { return rr(n * is); }
 };
 
+// sin and cos of an angle known to lie within a few turns of zero (|x| < 100), for the slerp angle in [0, pi] of
+// a moving primitive.  The general routine carries an argument reduction for angles up to 1e308 that this never
+// needs; here the quarter turn count is small, so k * (the leading 33 bits of pi/2) is exact and two
+// subtractions reduce the angle to [-pi/4, pi/4] with an absolute error of about 1e-20, and the two polynomials
+// are the usual minimax ones for that interval (error below one unit in the last place of the result).
+// Not for directions the reference computes with sin and cos themselves (lobe, lens and light samples): those
+// have to come out bit for bit, and the library's do; the interpolated transform is already composed by other
+// formulas than the reference's, equal to about 1e-16.
+DEV void sincos_bounded(double x, double *sn, double *cs) {
+  const double k = rint(x * 0.63661977236758134308);  // 2 / pi
+  const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = ps * z - 2.50507602534068634195e-08;
+  ps = ps * z + 2.75573137070700676789e-06;
+  ps = ps * z - 1.98412698298579493134e-04;
+  ps = ps * z + 8.33333333332248946124e-03;
+  ps = ps * z - 1.66666666666666324348e-01;
+  const double s = r + (r * z) * ps;
+  double pc = -1.13596475577881948265e-11;
+  pc = pc * z + 2.08757232129817482790e-09;
+  pc = pc * z - 2.75573143513906633035e-07;
+  pc = pc * z + 2.48015872894767294178e-05;
+  pc = pc * z - 1.38888888888741095749e-03;
+  pc = pc * z + 4.16666666666666019037e-02;
+  const double c = (1.0 - 0.5 * z) + (z * z) * pc;
+  const int q = (int)k;
+  const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+  *sn = (q & 2) ? -a : a;
+  *cs = ((q + 1) & 2) ? -b : b;
+}
+
 // Mat4::interpolate (Transform.cpp:239-256) with the decomposition already done: lerp T and S,
 // slerp or normalised lerp R (Quaternion.h:73-116), compose (Transform.cpp:209-236).
 DEV XfG motion_general(const RO DMotion &mo, double t) {
@@ -186,7 +218,7 @@ DEV XfG motion_general(const RO DMotion &mo, double t) {
   } else {
     const double th = mo.theta0 * t;
     double sn, cs;
-    sincos(th, &sn, &cs);
+    sincos_bounded(th, &sn, &cs);
     const double k1 = sn * mo.inv_sin0;
     const double k0 = cs - mo.dot * k1;
     qw = k0 * mo.q0[0] + k1 * mo.dq[0];

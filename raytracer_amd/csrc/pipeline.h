@@ -31,14 +31,18 @@
 #define WAVE 64
 
 // Register budget of the two big kernels, as waves per SIMD the compiler must make room for.  The
-// packet walk is bound by fp64 issue: three waves without (much) spilling beat four with.  The
-// per-lane walks wait on dependent node fetches most of the time: there a fourth wave is worth more
-// than the registers it takes away (measured 12 % on a million primitives).
+// packet walk is bound by instruction issue, one wave's scalar and vector instructions in turn: a fourth
+// wave is worth 3 % (k_trace) to 10 % (k_shadow with strata) once the kernels fit 128 registers without
+// spilling, which they do since loop-invariant constants are no longer hoisted (see the Makefile) and the
+// kernel arguments are read where they are needed (args_again); the variants that carry texture
+// coordinates, and the shadow walk that chains segments through attenuating surfaces, need more and stay
+// at three.  The per-lane walks wait on dependent node fetches most of the time: there a fourth wave is
+// worth more than the registers it takes away (measured 12 % on a million primitives).
 #ifndef MIRT_TRACE_WAVES
-#define MIRT_TRACE_WAVES 3
+#define MIRT_TRACE_WAVES 4
 #endif
 #ifndef MIRT_SHADOW_WAVES
-#define MIRT_SHADOW_WAVES 3
+#define MIRT_SHADOW_WAVES 4
 #endif
 #ifndef MIRT_LANE_WALK_WAVES
 #define MIRT_LANE_WALK_WAVES 4
@@ -988,6 +992,25 @@ DEV void progress_mark(const TraceArgs &a, uint32_t vb, bool finished) {
   else atomicMin(a.progress, now);
 }
 
+// The kernel's argument block, read afresh.  The compiler loads every argument field a kernel uses at its
+// entry and, out of scalar registers long before the walk is over, parks them in lanes of vector registers and
+// fetches them back one by one when the shading needs them (a hundred lane writes at the top of k_trace, several
+// hundred lane reads in its shading section).  A pointer to the argument segment that has passed through an
+// empty asm is a pointer the compiler knows nothing about: what is read through it is read after that point,
+// from the scalar cache, when it is needed.  Only for kernels whose one parameter is the block itself.
+#ifndef MIRT_ARGS_AGAIN
+#define MIRT_ARGS_AGAIN 1
+#endif
+template <class A> DEV const A &args_again(const A &a) {
+#if MIRT_ARGS_AGAIN
+  const RO A *p = (const RO A *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const A *)p;
+#else
+  return a;
+#endif
+}
+
 // One ray of a trace launch: where it comes from.
 struct RaySeed {
   d3 ro, rd, W;  // origin, direction, the RGB weight with which its radiance enters the pixel
@@ -1239,6 +1262,9 @@ DEV void shade_hits(const TraceArgs &a, const DRayQueue &out, const LevelVar &lv
       const d3 w = r;
       const d3 u = unit(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
       const d3 v = cross(w, u);
+      // (library pow and sincos on purpose: a lobe direction that differs from the reference's in its last bit
+      // sends the ray to the other of two coincident surfaces -- Test4's cylinder on its plane -- in a dozen
+      // pixels of a small frame; the short forms were 11 % faster on Test5 with 8 lobe samples)
       const double expo = pow(10.0, (lobe ? m.glossiness : 0.0) * 4.0);
       const d3 cws = cw / (double)samples;
       const uint32_t rank = (uint32_t)__popcll(m_lobe & below);
@@ -1303,7 +1329,7 @@ DEV void trace_block(const TraceArgs &a, const DRayQueue &in, const DRayQueue &o
   park_key[threadIdx.x] = r.key;
   park_pixel[threadIdx.x] = r.pixel;
   PARK_FENCE();
-  traverse<WALK, false, UV, MOTION>(sc, ray, active, 1e-5, closest, best, n_node, n_prim);
+  traverse<WALK, false, UV, MOTION>(args_again(a).sc, ray, active, 1e-5, closest, best, n_node, n_prim);
   PARK_FENCE();
   const d3 W = mk(park_w[0][threadIdx.x], park_w[1][threadIdx.x], park_w[2][threadIdx.x]);
   const uint64_t key = park_key[threadIdx.x];
@@ -1311,7 +1337,10 @@ DEV void trace_block(const TraceArgs &a, const DRayQueue &in, const DRayQueue &o
 #if MIRT_PROFILE == 1
   PROF_MARK(1);
 #endif
-  shade_hits<UV>(a, out, lv, shard, ray, best, active, W, key, pixel);
+  {
+    const TraceArgs &as = args_again(a);
+    shade_hits<UV>(as, as.out, level_of(as), shard, ray, best, active, W, key, pixel);
+  }
   if (PRIMARY) progress_mark(a, vb, true);
 #if MIRT_PROFILE == 1
   PROF_MARK(2);
@@ -1322,7 +1351,7 @@ DEV void trace_block(const TraceArgs &a, const DRayQueue &in, const DRayQueue &o
 // PRIMARY: one grid block per (pixel block, sample).  Otherwise the grid has a fixed size and its
 // blocks stride over the virtual blocks of the input queue, whose length only the device knows.
 template <bool PRIMARY, bool UV, bool MOTION, int WALK>
-__global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
+__global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, UV ? 3 : MIRT_TRACE_WAVES) void k_trace(const TraceArgs a) {
   unsigned n_node = 0, n_prim = 0;
   const LevelVar lv = level_of(a);
   if (PRIMARY) {
@@ -1631,9 +1660,9 @@ DEV void shadow_block_items(const ShadowArgs &a, const LightTable &lights, bool 
     PROF_MARK(2);
 #endif
     if constexpr (ANYHIT && WALK == WALK_PACKET)
-      traverse_packet<true, false, false, true>(sc, ray, busy, eps, closest, best, n_node, n_prim, dist - cur);
+      traverse_packet<true, false, false, true>(args_again(a).sc, ray, busy, eps, closest, best, n_node, n_prim, dist - cur);
     else
-      traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+      traverse<WALK, true, false, false>(args_again(a).sc, ray, busy, eps, closest, best, n_node, n_prim);
 #if MIRT_PROFILE == 2
     PROF_MARK(1);
 #endif
@@ -1711,10 +1740,11 @@ DEV void shadow_block_point(const ShadowArgs &a, const LightTable &lights, bool 
   best.t = 0;
   if (busy) n_seg++;
   PARK_FENCE();
-  traverse_packet<true, false, false, true>(sc, ray, busy, eps, closest, best, n_node, n_prim, limit);
+  traverse_packet<true, false, false, true>(args_again(a).sc, ray, busy, eps, closest, best, n_node, n_prim, limit);
   PARK_FENCE();
   const bool occluded = busy && best.prim >= 0 && best.t < limit;
-  pixel_add_wave(a.accum, a.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]), valid && !occluded);
+  const ShadowArgs &ap = args_again(a);
+  pixel_add_wave(ap.accum, ap.fr.plane, park_pixel[tid], mk(park_c[0][tid], park_c[1][tid], park_c[2][tid]), valid && !occluded);
 }
 
 // Raytracer::compute_shadow (Raytracer.cpp:145-208) for the 64 (hit, light) items of a wave, when some
@@ -1857,9 +1887,9 @@ DEV void shadow_block_strata(const ShadowArgs &a, const LightTable &lights, bool
     PROF_MARK(2);
 #endif
     if constexpr (ANYHIT && WALK == WALK_PACKET)
-      traverse_packet<true, false, false, true>(sc, ray, busy, eps, closest, best, n_node, n_prim, dist - cur);
+      traverse_packet<true, false, false, true>(args_again(a).sc, ray, busy, eps, closest, best, n_node, n_prim, dist - cur);
     else
-      traverse<WALK, true, false, false>(sc, ray, busy, eps, closest, best, n_node, n_prim);
+      traverse<WALK, true, false, false>(args_again(a).sc, ray, busy, eps, closest, best, n_node, n_prim);
 #if MIRT_PROFILE == 2
     PROF_MARK(1);
 #endif
@@ -1898,11 +1928,8 @@ DEV void shadow_block_strata(const ShadowArgs &a, const LightTable &lights, bool
 // STRATA: some light of the frame has more than one stratum.
 // ANYHIT (packet walk only): see traverse_packet; a stratum is then one segment, never a chain.
 // POINT (with ANYHIT, the packet walk and no strata only): no light of the scene is an area light
-#ifndef MIRT_SHADOW_POINT_WAVES
-#define MIRT_SHADOW_POINT_WAVES 4
-#endif
 template <int WALK, bool STRATA, bool ANYHIT = false, bool POINT = false>
-__global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, POINT ? MIRT_SHADOW_POINT_WAVES : MIRT_SHADOW_WAVES) void k_shadow(const ShadowArgs a) {
+__global__ __launch_bounds__(256) WAVES_FOR_WALK(WALK, ANYHIT ? MIRT_SHADOW_WAVES : 3) void k_shadow(const ShadowArgs a) {
   unsigned n_node = 0, n_prim = 0, n_seg = 0;
   __shared__ LightTable lights;
   light_table_fill(lights, a.sc, a.fr);
