@@ -146,10 +146,12 @@ def test_random_rays_vs_oracle(name, host_scenes, device_scenes):
     assert np.allclose(got["normal"][ok], ref["normal"][ok], atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["t5_glossy", "t7_dof_soft", "t2_texture"])
+@pytest.mark.parametrize("case", ["t5_glossy", "t7_dof_soft", "t2_texture", "t1_cfg0", "t4_glossy3"])
 def test_lane_walk_renders_what_packet_walk_renders(case, host_scenes, device_scenes):
     """Same rays, same tests per ray, same addressed draws: the two BVH walks differ only in the
-    order in which the fp64 atomics reach a pixel."""
+    order in which the fp64 atomics reach a pixel.  (Test1 and Test5 have point lights only and no attenuating
+    glass: their packet-walk shadow items run as one any-hit segment each, the lane walk's as chained closest
+    hits; Test4's glass attenuates, Test7's lights are areas.)"""
     scene, dof, over = RENDER_CASES[case]
     hs = host_scenes(scene)
     cam, _ = hs.camera(0, dof=dof)
