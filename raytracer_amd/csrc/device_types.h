@@ -25,7 +25,7 @@ struct alignas(64) DNode {
   int32_t skip;   // next node in depth-first order after this subtree
   int32_t first;  // leaf: first entry in leaf_prims; inner node: -1
   int32_t count;  // leaf: number of primitives; inner node: index of the second child (the first is this + 1)
-  int32_t order;  // inner node: bits 0-1 axis along which the children lie furthest apart, bit 2: second child is the lower one
+  int32_t order;  // inner node: bits 0-1 axis along which the children lie furthest apart, bit 2: second child is the lower one; leaf: leaf_tagged[first] (0 when empty)
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte record");
 

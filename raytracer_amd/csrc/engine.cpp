@@ -909,6 +909,9 @@ int scene_create(const mirt_scene_desc *desc, int device, const mirt_build_optio
     std::vector<int32_t> tagged(leaf);
     for (auto &t : tagged)
       t |= (s.prims[t].type << LEAF_KIND_SHIFT) | (transparency[t] == 1.0 ? LEAF_CLEAR_BIT : 0);
+    // a leaf's first primitive rides in its node record: the packet walk then reaches it without a trip to leaf_tagged
+    for (auto &n : nodes)
+      if (n.first >= 0) n.order = n.count > 0 ? tagged[n.first] : 0;
     HIP_TRY(upload(sc->nodes, nodes));
     HIP_TRY(upload(sc->leaf_prims, leaf));
     HIP_TRY(upload(sc->leaf_tagged, tagged));
