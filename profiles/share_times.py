@@ -56,18 +56,20 @@ def main():
             for slot in range(depth):  # sizes the working memory
                 begin(slot)
                 st = ds.render_tiles_end(slot)
-            t0 = time.perf_counter()
-            for _ in range(args.frames):
-                begin(0)
-                st = ds.render_tiles_end(0)
-            alone = (time.perf_counter() - t0) / args.frames * 1e3
-            t0 = time.perf_counter()
-            for i in range(args.frames + depth):
-                if i >= depth:
-                    ds.render_tiles_end(i % depth)
-                if i < args.frames:
-                    begin(i % depth)
-            pipelined = (time.perf_counter() - t0) / args.frames * 1e3
+            alone = pipelined = float("inf")
+            for _ in range(2):  # the better of two runs each: the first run after a change of share can catch the clocks ramping
+                t0 = time.perf_counter()
+                for _ in range(args.frames):
+                    begin(0)
+                    st = ds.render_tiles_end(0)
+                alone = min(alone, (time.perf_counter() - t0) / args.frames * 1e3)
+                t0 = time.perf_counter()
+                for i in range(args.frames + depth):
+                    if i >= depth:
+                        ds.render_tiles_end(i % depth)
+                    if i < args.frames:
+                        begin(i % depth)
+                pipelined = min(pipelined, (time.perf_counter() - t0) / args.frames * 1e3)
             ranks.append({"rank": rank, "ms_one_at_a_time": alone, "ms_two_in_flight": pipelined,
                           "device_ms": st["device_ms"], "rays": st["primary_rays"] + st["secondary_rays"],
                           "shadow_segments": st["shadow_segments"], "launches": st["launches"]})
