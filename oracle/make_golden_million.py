@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  tests/golden/hits_synthetic1m.npz: closest hits and depth-5 colours of the generated cloud
+of 10^6 primitives (raytracer_amd/host/synthetic.h, seed 0x5EED: the large-scene bench configuration) from the
+reference renderer itself, which reads the cloud through its own parser as an ASCII file of about a gigabyte.
+Kept apart from oracle/make_goldens.py because it takes minutes and gigabytes where that takes seconds.
+
+Run in the build container (needs oracle/_ref/ref_harness, built by `make -C oracle ref`):
+    python oracle/make_golden_million.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+OUT = os.path.join(ROOT, "tests", "golden")
+NAME, COUNT, SEED = "synthetic1m", 1000000, 0x5EED
+W, H = 96, 54
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` where /root/reference exists")
+    sys.path.insert(0, ROOT)
+    from raytracer_amd import HostScene
+    n = W * H
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "ASCII"))
+        t0 = time.time()
+        HostScene.synthetic(COUNT, SEED).write_ascii(os.path.join(tmp, "ASCII", f"{NAME}.txt"))
+        print("scene file", os.path.getsize(os.path.join(tmp, "ASCII", f"{NAME}.txt")) >> 20, "MiB,",
+              round(time.time() - t0, 1), "s", flush=True)
+        out = os.path.join(tmp, "h.bin")
+        t0 = time.time()
+        subprocess.run([HARNESS, "--root", tmp, "hits", f"ASCII/{NAME}.txt", str(W), str(H), out], check=True)
+        print("hits", round(time.time() - t0, 1), "s", flush=True)
+        raw = np.fromfile(out, dtype=np.uint8)
+        ids = raw[: 4 * n].view(np.int32)
+        front = raw[4 * n: 8 * n].view(np.int32)
+        rest = raw[8 * n:].view(np.float64)
+        t0 = time.time()
+        subprocess.run([HARNESS, "--root", tmp, "trace", f"ASCII/{NAME}.txt", str(W), str(H), out, "--max-depth", "5",
+                        "--motion-blur", "0"], check=True)
+        print("trace", round(time.time() - t0, 1), "s", flush=True)
+        rgb = np.fromfile(out, dtype=np.float64)
+        np.savez_compressed(
+            os.path.join(OUT, f"hits_{NAME}.npz"), width=W, height=H, prim_id=ids, front=front, t=rest[:n],
+            normal=rest[n: 4 * n].reshape(n, 3), point=rest[4 * n: 7 * n].reshape(n, 3),
+            uv=rest[7 * n: 9 * n].reshape(n, 2), trace_rgb_depth5=rgb.reshape(n, 3))
+        print(NAME, "hit fraction", float((ids >= 0).mean()))
+
+
+if __name__ == "__main__":
+    main()

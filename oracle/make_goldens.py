@@ -24,7 +24,9 @@ SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_sc
 # for the engine's large-scene walk; hits and colours only
 TIES = ["Test4_ties"]
 W, H = 96, 54  # deterministic (pixel-centre) maps
-SYNTHETIC = [("synthetic100k", 100000, 0x5EED)]  # generated scenes (raytracer_amd/host/synthetic.h): a deep BVH
+# generated scenes (raytracer_amd/host/synthetic.h): a deep BVH; the cloud of 10^6 has a script of its own
+# (oracle/make_golden_million.py: minutes and gigabytes)
+SYNTHETIC = [("synthetic100k", 100000, 0x5EED)]
 
 # stochastic renders: (name, scene, w, h, spp, harness flags); tests/golden_cases.py maps the flags
 # to mirt_config fields

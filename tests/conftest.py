@@ -20,8 +20,8 @@ SCENES = ["Test1", "Test2", "Test3", "Test4", "Test5", "Test6", "Test7", "def_sc
 # primitives at which the engine chooses its large-scene walk; hits and depth-5 colours from the reference
 TIES = ["Test4_ties"]
 # generated scenes (raytracer_amd/host/synthetic.h): name -> (primitives, seed); oracle/make_goldens.py
-# feeds the same scenes to the reference as ASCII files
-SYNTHETIC = {"synthetic100k": (100000, 0x5EED)}
+# (and, for the cloud of a million, oracle/make_golden_million.py) feed the same scenes to the reference as ASCII files
+SYNTHETIC = {"synthetic100k": (100000, 0x5EED), "synthetic1m": (1000000, 0x5EED)}
 
 
 def scene_path(name):

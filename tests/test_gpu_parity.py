@@ -459,7 +459,8 @@ def million(host_scenes):
 
 def test_million_primitive_cloud_vs_oracle(million):
     """Closest hits and a stochastic frame of the 10^6-primitive cloud at a resolution the oracle
-    finishes in seconds (the oracle is pinned bit for bit to the reference on the 10^5 sibling)."""
+    finishes in seconds (the oracle reproduces the reference's own hits and colours of this very cloud bit for
+    bit: tests/golden/hits_synthetic1m.npz, tests/test_oracle_golden.py)."""
     hs, ds = million
     cam, _ = hs.camera(0)
     w, h = 192, 108
