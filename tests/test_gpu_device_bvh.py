@@ -146,6 +146,23 @@ def test_million_primitive_cloud_on_the_device_tree(million):
     assert p >= 60.0 and mae <= 2e-5 and off.mean() <= 1e-2  # far tori: see test_million_primitive_cloud_vs_oracle
 
 
+def test_million_primitive_cloud_on_the_device_tree_vs_reference_golden(million):
+    """The tree the bench uses for its large-scene configuration, against the reference's own hits and depth-5
+    colours of that cloud (tests/golden/hits_synthetic1m.npz, oracle/make_golden_million.py)."""
+    hs, dd = million
+    cam, _ = hs.camera(0)
+    gold = np.load(os.path.join(GOLDEN, "hits_synthetic1m.npz"))
+    got = dd.trace_ids(cam, 96, 54)
+    same = got["prim_id"] == gold["prim_id"]
+    print(f"10^6 cloud, device tree: prim-id agreement with the reference {same.mean():.6f}")
+    assert same.mean() >= 0.999
+    cfg = default_config(max_ray_depth=5, enable_motion_blur=0, sampling=1, enable_gamma_correction=0)
+    frame, _ = dd.render(cam, cfg, 96, 54, 1)
+    p = O.psnr(frame, gold["trace_rgb_depth5"].reshape(54, 96, 3))
+    print(f"10^6 cloud, device tree: depth-5 colours vs the reference {p:.1f} dB")
+    assert p >= 60.0
+
+
 def test_million_primitive_cloud_at_4k_on_the_device_tree(million):
     from test_gpu_parity import crop_vs_oracle
     hs, dd = million
