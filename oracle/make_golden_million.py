@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE.  tests/golden/hits_synthetic1m.npz: closest hits and depth-5 colours of the generated cloud
+"""TEST INFRASTRUCTURE.  tests/golden/hits_synthetic1m.npz and render_s1m_cfg4.npz: closest hits, depth-5 colours and
+a stochastic frame (jitter, motion blur) of the generated cloud
 of 10^6 primitives (raytracer_amd/host/synthetic.h, seed 0x5EED: the large-scene bench configuration) from the
 reference renderer itself, which reads the cloud through its own parser as an ASCII file of about a gigabyte.
 Kept apart from oracle/make_goldens.py because it takes minutes and gigabytes where that takes seconds.
@@ -52,6 +53,18 @@ def main():
             normal=rest[n: 4 * n].reshape(n, 3), point=rest[4 * n: 7 * n].reshape(n, 3),
             uv=rest[7 * n: 9 * n].reshape(n, 2), trace_rgb_depth5=rgb.reshape(n, 3))
         print(NAME, "hit fraction", float((ids >= 0).mean()))
+        # a stochastic frame with the large-scene bench configuration's flags (jitter, motion blur, depth 5): the
+        # reference's own trace() under the harness's pixel loop, its generators fed the known stream
+        w, h, spp = 48, 27, 2
+        t0 = time.time()
+        r = subprocess.run([HARNESS, "--root", tmp, "render", f"ASCII/{NAME}.txt", str(w), str(h), str(spp), out,
+                            "--max-depth", "5"], check=True, capture_output=True)
+        print("render", round(time.time() - t0, 1), "s", flush=True)
+        prim_tests = int(r.stderr.decode().split()[1])
+        rgb = np.fromfile(out, dtype=np.float64).reshape(h * w, 3)
+        np.savez_compressed(os.path.join(OUT, "render_s1m_cfg4.npz"), width=w, height=h, spp=spp, rgb=rgb,
+                            prim_tests=prim_tests)
+        print("s1m_cfg4 mean", float(rgb.mean()), "prim_tests", prim_tests)
 
 
 if __name__ == "__main__":

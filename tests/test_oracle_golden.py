@@ -53,6 +53,18 @@ def test_stochastic_render_bit_exact(case, host_scenes):
     assert st["prim_tests"] == int(gold["prim_tests"])  # g_intersection_tests of the reference
 
 
+def test_stochastic_render_of_the_million_primitive_cloud_bit_exact(host_scenes):
+    """The large-scene bench configuration's flags (jitter, motion blur on, depth 5) on its own cloud of 10^6
+    primitives, the reference's generators fed the same sequential stream (oracle/make_golden_million.py)."""
+    hs = host_scenes("synthetic1m")
+    gold = np.load(os.path.join(GOLDEN, "render_s1m_cfg4.npz"))
+    w, h, spp = int(gold["width"]), int(gold["height"]), int(gold["spp"])
+    cam, _ = hs.camera(0)
+    rgb, st = O.render(hs.desc, cam, default_config(max_ray_depth=5), w, h, spp, O.RNG_SEQUENTIAL)
+    assert np.array_equal(rgb.reshape(-1, 3), gold["rgb"])
+    assert st["prim_tests"] == int(gold["prim_tests"])  # g_intersection_tests of the reference
+
+
 @pytest.mark.parametrize("case", sorted(REAL_CASES))
 def test_frames_of_the_reference_render_function_bit_exact(case, host_scenes):
     """Raytracer::render ITSELF (Raytracer.cpp:475-607: sample loop, mean, Reinhard / exposure tone
