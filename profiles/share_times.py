@@ -15,6 +15,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # as bench.py: kernel arguments in device memory
 
 PRESETS = {
     "cfg2": dict(scene="Test5", width=1920, height=1080, spp=16, over=dict(max_ray_depth=5)),

@@ -97,6 +97,8 @@ int main(int argc, char *argv[]) {
     return 0;
   }
   parse_arguments(argc, argv);
+  // kernel arguments in device memory (the HIP runtime reads this when it starts, which is at the first render)
+  setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
   if (g_config.scene_file.empty()) {
     host_log(LogLevel::Error, "No scene file specified");
     print_help(argv[0]);
